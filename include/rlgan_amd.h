@@ -1,0 +1,223 @@
+/*
+ * rlgan_amd.h -- C ABI of librlgan_amd.so: the MI355X (gfx950) hot path of RL-GAN.
+ *
+ * The reference (hithmh/RL-GAN, directory GAN-RL/) is pure Python + TensorFlow 1.x and has no
+ * FFI layer of its own; every entry point below replaces one group of `sess.run` / NumPy calls
+ * and cites it.  All pointers marked "device" are HIP device pointers owned by the caller (the
+ * Python layer allocates them as torch tensors); the library only enqueues work on `stream`
+ * (a hipStream_t passed as void*) and never allocates, frees or synchronises.
+ *
+ * Return value of every function: 0 = ok, < 0 = argument error (RLGAN_E_*), > 0 = hipError_t.
+ * No C++ exception crosses this boundary.
+ *
+ * Network kinds and tensor layouts
+ * --------------------------------
+ * A network is held three ways on the device:
+ *   canon : flat fp32 vector, tensors in TensorFlow variable-creation order, each row-major
+ *           [in, out] (DDPG.py:78-95,153-172; Curious_GAN.py:46-82,112-135);
+ *   wf    : "forward fragments" -- per layer the matrix [W ; b] ((K+1) x N, bias as last row) cut
+ *           into MFMA 16x16x4 B-operand fragments: float index ((step*NT + tile)*64 + lane) holds
+ *           element (k = 4*step + lane/16, n = 16*tile + lane%16), zero outside the matrix;
+ *   wb    : "backward fragments" -- the same for W^T (N x K, no bias) used for dX = dZ * W^T.
+ * `rlgan_build_maps` gives, per canonical parameter, its float offset in wf, wb and in the padded
+ * gradient image the weight-gradient kernel writes.
+ */
+#ifndef RLGAN_AMD_H
+#define RLGAN_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RLGAN_ABI_VERSION 1
+
+enum { RLGAN_NET_ACTOR = 0, RLGAN_NET_CRITIC = 1, RLGAN_NET_GENERATOR = 2, RLGAN_NET_DISCRIMINATOR = 3 };
+
+enum {
+  RLGAN_E_ARG = -1,      /* null pointer / negative size */
+  RLGAN_E_DIMS = -2,     /* state/action dims outside what the kernels are built for */
+  RLGAN_E_KIND = -3,     /* unknown network kind */
+  RLGAN_E_NOTFULL = -4,  /* replay sample before the ring is full (Curious_GAN.py:167 assert) */
+  RLGAN_E_ALIGN = -5     /* row count / leading dimension not as documented */
+};
+
+/* sizes of the three device images of one network */
+typedef struct {
+  int32_t n_params;   /* canon length */
+  int32_t wf_floats;  /* forward-fragment image length */
+  int32_t wb_floats;  /* backward-fragment image length */
+  int32_t gpad_floats;/* padded gradient image length (one batch chunk) */
+  int32_t k0;         /* first-layer input width (sum of input blocks, without the bias row) */
+  int32_t n3;         /* width of the third layer (10 or 50) */
+  int32_t n_out;      /* output width */
+  int32_t ld3;        /* leading dimension of the h3 / dz3 work arrays (16 or 64) */
+} rlgan_geom_t;
+
+/* device images of one network as the kernels consume them */
+typedef struct {
+  const float* wf;    /* device, forward fragments (required) */
+  const float* wb;    /* device, backward fragments (NULL for forward-only use) */
+} rlgan_net_t;
+
+/* per-network activation / pre-activation-gradient work arrays written by a *_rows kernel and
+ * consumed by rlgan_weight_grads.  Row-major, `rows` rows (a multiple of 16), leading dimensions:
+ * x0: 32, h1/h2/dz1/dz2: 208, h3/dz3: geom.ld3, dz4: 16.  All device. */
+typedef struct {
+  float* x0;  float* h1;  float* h2;  float* h3;
+  float* dz1; float* dz2; float* dz3; float* dz4;
+} rlgan_acts_t;
+
+/* a [rows, width] fp32 matrix on the device with an arbitrary row stride (in floats) */
+typedef struct { const float* p; int32_t ld; } rlgan_mat_t;
+
+const char* rlgan_error_string(int code);
+int rlgan_abi_version(void);
+
+/* ---- geometry / layout helpers (host-side, no GPU work) ------------------------------- */
+int rlgan_geometry(int kind, int s_dim, int a_dim, rlgan_geom_t* out);
+/* host arrays of n_params int32 each; map_b may be NULL.  Offsets of -1 mean "not present". */
+int rlgan_build_maps(int kind, int s_dim, int a_dim, int32_t* map_f, int32_t* map_b, int32_t* map_g);
+/* rows per batch chunk and chunk count the weight-gradient kernel will use for `rows` rows */
+int rlgan_wgrad_chunks(int rows, int32_t* chunk_rows, int32_t* n_chunks);
+
+/* scatter canon -> wf (and wb when non-NULL).  wf/wb must have been zero-filled once. */
+int rlgan_pack_weights(const float* canon, int n_params, const int32_t* map_f, float* wf,
+                       const int32_t* map_b, float* wb, void* stream);
+
+/* ---- forward passes (acting path) ------------------------------------------------------
+ * Actor.choose_action DDPG.py:103-105; Generator.predict Curious_GAN.py:150-153;
+ * Discriminator.determine Curious_GAN.py:87-92; batched forms follow Conv_model.py:296,562.
+ * Inputs by kind: actor (s); critic (s, a); generator (s, a); discriminator (s, x, a).
+ * out_mode: 0 = network output, 1 = sigmoid(output), 2 = 1 - sigmoid(output) ("determine"). */
+int rlgan_mlp_forward(int kind, int s_dim, int a_dim, rlgan_net_t net,
+                      rlgan_mat_t s, rlgan_mat_t x, rlgan_mat_t a,
+                      float* out, int ld_out, int out_mode, int n_rows, void* stream);
+
+/* ---- the four update steps: row passes ---------------------------------------------------
+ * Each processes 16-row tiles of the minibatch: forward, loss, backward-to-inputs, and leaves the
+ * per-layer inputs and pre-activation gradients in `acts` for rlgan_weight_grads.
+ * `inv_global_batch` = 1 / (batch rows summed over all data-parallel ranks).
+ * `loss_parts` receives one partial SUM per 16-row tile (n_tiles = ceil(n_rows/16)).           */
+
+/* Critic.learn DDPG.py:141-148,174-175: y = r + gamma*q'(s_, a'(s_)); L = mean (y-q(s,a))^2.
+ * When `actor_eval.wf` is non-NULL the gradient is continued into the actor eval net with TanhGrad
+ * taken at the fed action (minimize() without var_list, DDPG.py:148) and `acts_actor` is filled. */
+int rlgan_critic_step_rows(int s_dim, int a_dim, rlgan_net_t critic_eval, rlgan_net_t critic_target,
+                           rlgan_net_t actor_target, rlgan_net_t actor_eval,
+                           rlgan_mat_t s, rlgan_mat_t a, rlgan_mat_t r, rlgan_mat_t s_next,
+                           float gamma, float inv_global_batch, int n_rows,
+                           rlgan_acts_t acts_critic, rlgan_acts_t acts_actor,
+                           float* loss_parts, void* stream);
+
+/* Actor.learn DDPG.py:97-98,107-113 with a_grads = d(sum q)/da (DDPG.py:151): batch-SUM gradient. */
+int rlgan_actor_step_rows(int s_dim, int a_dim, rlgan_net_t actor_eval, rlgan_net_t critic_eval,
+                          rlgan_mat_t s, int n_rows, rlgan_acts_t acts_actor, void* stream);
+
+/* Discriminator.learn Curious_GAN.py:33-45,84-85.  acts_disc has 2*rows16 rows: fake rows first
+ * (x = stored G sample), then real rows (x = s_next).  loss_parts: fake+real CE sum per tile. */
+int rlgan_disc_step_rows(int s_dim, int a_dim, rlgan_net_t disc,
+                         rlgan_mat_t s, rlgan_mat_t g_stored, rlgan_mat_t a, rlgan_mat_t s_next,
+                         float label_real, float inv_global_batch, int n_rows,
+                         rlgan_acts_t acts_disc, float* loss_parts, void* stream);
+
+/* Generator.learn Curious_GAN.py:137-145: L = mean CE(D_logit(s, a, G(s,a)), 1), dX through D. */
+int rlgan_gen_step_rows(int s_dim, int a_dim, rlgan_net_t gen, rlgan_net_t disc,
+                        rlgan_mat_t s, rlgan_mat_t a, float inv_global_batch, int n_rows,
+                        rlgan_acts_t acts_gen, float* loss_parts, void* stream);
+
+/* Discriminator.eval + Generator.eval Curious_GAN.py:94-95,147-148 in one pass.
+ * loss_parts: [2][n_tiles] -- D loss sums then G loss sums. */
+int rlgan_gan_eval_rows(int s_dim, int a_dim, rlgan_net_t gen, rlgan_net_t disc,
+                        rlgan_mat_t s, rlgan_mat_t g_stored, rlgan_mat_t a, rlgan_mat_t s_next,
+                        float label_real, int n_rows, float* loss_parts, void* stream);
+
+/* ---- weight gradients, reduction, optimizers ------------------------------------------------ */
+/* dW_l = X_l^T dZ_l (bias gradient = the row of the constant-one input column) for the four layers
+ * of one network, batch rows split into n_chunks chunks; chunk c writes its partial image at
+ * gslabs + c*gpad_floats.  `rows` is the row count of the acts arrays (multiple of 16). */
+int rlgan_weight_grads(int kind, int s_dim, int a_dim, rlgan_acts_t acts, int rows,
+                       float* gslabs, void* stream);
+
+/* grad[p] = sum_c gslabs[c*gpad_floats + map_g[p]] in chunk order (bitwise reproducible);
+ * optional: loss_out[0] = loss_scale * sum(loss_parts[0..n_parts)), counter[0] += 1. */
+int rlgan_grad_reduce(const float* gslabs, int n_chunks, int gpad_floats, const int32_t* map_g,
+                      int n_params, float* grad, const float* loss_parts, int n_parts,
+                      float loss_scale, float* loss_out, int32_t* counter, void* stream);
+
+/* tf.train.RMSPropOptimizer (DDPG.py:112,148): ms <- decay*ms+(1-decay)*g^2 (ms starts at 1),
+ * w <- w - lr*g/sqrt(ms+eps).  Writes canon and its fragment images. */
+int rlgan_rmsprop_apply(float* canon, const float* grad, float* ms, int n_params,
+                        float lr, float decay, float eps,
+                        const int32_t* map_f, float* wf, const int32_t* map_b, float* wb, void* stream);
+
+/* tf.train.AdamOptimizer (Curious_GAN.py:45,142): lr_t = lr*sqrt(1-b2^t)/(1-b1^t), t = step[0]
+ * (already incremented for this step, e.g. by rlgan_grad_reduce); eps outside the sqrt. */
+int rlgan_adam_apply(float* canon, const float* grad, float* m, float* v, int n_params,
+                     double lr, double beta1, double beta2, float eps, const int32_t* step,
+                     const int32_t* map_f, float* wf, const int32_t* map_b, float* wb, void* stream);
+
+/* target <- tau*eval + (1-tau)*target when (counter[0]-1) % period == 0 (counter NULL: always).
+ * The reference only has the hard copy, tau = 1 (DDPG.py:99-101,176-178). */
+int rlgan_target_update(float* target_canon, const float* eval_canon, int n_params, float tau,
+                        const int32_t* counter, int period, const int32_t* map_f, float* target_wf,
+                        void* stream);
+
+/* ---- environment ---------------------------------------------------------------------------
+ * ArmEnv.step / _get_state / _r_func arm_env.py:43-59,91-115, one thread per environment, float64.
+ * State arrays (device, struct of arrays, n_env each): theta[2n] (th1,th2 interleaved), ends[4n]
+ * (x1,y1,x2,y2), goal[2n] (integer-valued doubles), grab[n] int32, got[n] uint8.
+ * action: [n,2] fp32 or fp64 (action_f64 != 0).  Outputs: state_out [n,7] double, state_out_f32
+ * [n,7] float (either may be NULL), reward[n] double, done[n] uint8. */
+typedef struct { double* theta; double* ends; double* goal; int32_t* grab; uint8_t* got; } rlgan_env_t;
+
+int rlgan_env_step(rlgan_env_t env, int n_env, const void* action, int action_f64, int ld_action,
+                   double* state_out, float* state_out_f32, double* reward, uint8_t* done, void* stream);
+
+/* ArmEnv.reset arm_env.py:61-78 for the environments with mask[i] != 0 (mask NULL: all).
+ * u: [n,2] uniform [0,1) doubles (the reference's np.random.rand(2)).  mode_hard: 1 = 'hard'. */
+int rlgan_env_reset(rlgan_env_t env, int n_env, int mode_hard, const uint8_t* mask, const double* u,
+                    double* state_out, float* state_out_f32, void* stream);
+
+/* Episode cut of the rollout loop (Curious_GAN.py:180,222-234): environment i is reset when
+ * done[i] != 0 or ep_t[i] >= max_ep_steps-1 (then ep_t[i] = 0 and its new state goes to
+ * state_f32[i,:]), otherwise ep_t[i] += 1.  n_resets (optional) counts resets. */
+int rlgan_env_autoreset(rlgan_env_t env, int n_env, int mode_hard, const uint8_t* done, int32_t* ep_t,
+                        int max_ep_steps, const double* u, float* state_f32, int32_t* n_resets, void* stream);
+
+/* ---- replay ring ----------------------------------------------------------------------------
+ * Memory.store_transition Curious_GAN.py:161-165 / DDPG.py:187-191 for n rows at once:
+ * data[(pointer+i) % capacity, :] = rows[i, :]; pointer is held by the caller.  The ring is fp32
+ * with row stride ld_data >= dims floats (32 makes every row one aligned 128-byte segment). */
+int rlgan_replay_store(float* data, int capacity, int dims, int ld_data, int64_t pointer, const float* rows,
+                       int ld_rows, int n_rows, void* stream);
+/* Memory.sample's fancy-index copy Curious_GAN.py:169: out[i,:] = data[idx[i],:]. */
+int rlgan_replay_gather(const float* data, int capacity, int dims, int ld_data, const int64_t* idx, int n,
+                        float* out, int ld_out, void* stream);
+
+/* np.random.choice(n_pop, size=n) on the legacy MT19937 stream (Curious_GAN.py:168): masked
+ * rejection over 32-bit outputs, bit-exact.  state: device uint32[625] = key[624] + position. */
+int rlgan_mt19937_seed(uint32_t* state, uint32_t seed, void* stream);
+int rlgan_mt19937_choice(uint32_t* state, int64_t n_pop, int n, int64_t* out_idx, void* stream);
+
+/* Philox4x32-10 draws for order-independent exploration noise and goal placement (no reference
+ * counterpart: the reference draws both from the global MT19937, Curious_GAN.py:191, arm_env.py:66).
+ * element i of `out` pairs: counter (index0+i), stream id `stream_id`, key `seed`. */
+int rlgan_philox_normal(float* out, int n_pairs, uint64_t seed, uint32_t stream_id, uint64_t index0, void* stream);
+int rlgan_philox_uniform(double* out, int n_pairs, uint64_t seed, uint32_t stream_id, uint64_t index0, void* stream);
+
+/* ---- fused acting path for n_env environments (Curious_GAN.py:190-195) ------------------------
+ * a = clip(actor(s) + var*noise, -1, 1); g = G(s, a); (s', r, done) = env.step(a);
+ * curious_r = r + ita*(1 - D(s, a, g)); row = [s, s', g, a, r, curious_r] -> replay ring at
+ * (pointer + env index) % capacity; s' is written back to state_f32 (the next step's input).
+ * noise: [n,2] standard normal fp32 (NULL: no noise).  var is read from device memory. */
+int rlgan_act_rows(int s_dim, int a_dim, rlgan_net_t actor_eval, rlgan_net_t gen, rlgan_net_t disc,
+                   rlgan_env_t env, int n_env, float* state_f32, const float* noise, const float* var,
+                   float ita, float* replay, int capacity, int dims, int ld_replay, int64_t pointer,
+                   double* reward_out, uint8_t* done_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RLGAN_AMD_H */

@@ -1,0 +1,110 @@
+"""ctypes binding of librlgan_amd.so (the C ABI declared in include/rlgan_amd.h).
+
+The library is the product: there is no Python or CPU fallback.  If it is missing the import
+fails with instructions to build it; if a call returns a non-zero status a RuntimeError carrying
+the library's own error string is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librlgan_amd.so")
+
+NET_ACTOR, NET_CRITIC, NET_GENERATOR, NET_DISCRIMINATOR = 0, 1, 2, 3
+KIND_NAMES = {NET_ACTOR: "actor", NET_CRITIC: "critic", NET_GENERATOR: "generator", NET_DISCRIMINATOR: "discriminator"}
+
+
+class Geom(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in
+                ("n_params", "wf_floats", "wb_floats", "gpad_floats", "k0", "n3", "n_out", "ld3")]
+
+
+class Net(C.Structure):
+    _fields_ = [("wf", C.c_void_p), ("wb", C.c_void_p)]
+
+
+class Acts(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("x0", "h1", "h2", "h3", "dz1", "dz2", "dz3", "dz4")]
+
+
+class Mat(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("ld", C.c_int32)]
+
+
+class Env(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("theta", "ends", "goal", "grab", "got")]
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `bash rl-gan_amd/csrc/build.sh` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`). "
+            "There is no CPU fallback for the RL-GAN hot path.")
+    return C.CDLL(LIB_PATH)
+
+
+lib = _load()
+
+_vp, _i, _f, _d, _i64, _u32, _u64 = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_int64, C.c_uint32, C.c_uint64
+
+# name -> argtypes; every function returns int except the two noted below.
+PROTOTYPES = {
+    "rlgan_abi_version": [],
+    "rlgan_geometry": [_i, _i, _i, C.POINTER(Geom)],
+    "rlgan_build_maps": [_i, _i, _i, _vp, _vp, _vp],
+    "rlgan_wgrad_chunks": [_i, C.POINTER(C.c_int32), C.POINTER(C.c_int32)],
+    "rlgan_pack_weights": [_vp, _i, _vp, _vp, _vp, _vp, _vp],
+    "rlgan_mlp_forward": [_i, _i, _i, Net, Mat, Mat, Mat, _vp, _i, _i, _i, _vp],
+    "rlgan_critic_step_rows": [_i, _i, Net, Net, Net, Net, Mat, Mat, Mat, Mat, _f, _f, _i, Acts, Acts, _vp, _vp],
+    "rlgan_actor_step_rows": [_i, _i, Net, Net, Mat, _i, Acts, _vp],
+    "rlgan_disc_step_rows": [_i, _i, Net, Mat, Mat, Mat, Mat, _f, _f, _i, Acts, _vp, _vp],
+    "rlgan_gen_step_rows": [_i, _i, Net, Net, Mat, Mat, _f, _i, Acts, _vp, _vp],
+    "rlgan_gan_eval_rows": [_i, _i, Net, Net, Mat, Mat, Mat, Mat, _f, _i, _vp, _vp],
+    "rlgan_weight_grads": [_i, _i, _i, Acts, _i, _vp, _vp],
+    "rlgan_grad_reduce": [_vp, _i, _i, _vp, _i, _vp, _vp, _i, _f, _vp, _vp, _vp],
+    "rlgan_rmsprop_apply": [_vp, _vp, _vp, _i, _f, _f, _f, _vp, _vp, _vp, _vp, _vp],
+    "rlgan_adam_apply": [_vp, _vp, _vp, _vp, _i, _d, _d, _d, _f, _vp, _vp, _vp, _vp, _vp, _vp],
+    "rlgan_target_update": [_vp, _vp, _i, _f, _vp, _i, _vp, _vp, _vp],
+    "rlgan_env_step": [Env, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "rlgan_env_reset": [Env, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "rlgan_env_autoreset": [Env, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp],
+    "rlgan_replay_store": [_vp, _i, _i, _i, _i64, _vp, _i, _i, _vp],
+    "rlgan_replay_gather": [_vp, _i, _i, _i, _vp, _i, _vp, _i, _vp],
+    "rlgan_mt19937_seed": [_vp, _u32, _vp],
+    "rlgan_mt19937_choice": [_vp, _i64, _i, _vp, _vp],
+    "rlgan_philox_normal": [_vp, _i, _u64, _u32, _u64, _vp],
+    "rlgan_philox_uniform": [_vp, _i, _u64, _u32, _u64, _vp],
+    "rlgan_act_rows": [_i, _i, Net, Net, Net, Env, _i, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _i64, _vp, _vp, _vp],
+}
+
+for _name, _args in PROTOTYPES.items():
+    _fn = getattr(lib, _name)          # AttributeError here = the .so is older than this binding
+    _fn.argtypes = _args
+    _fn.restype = C.c_int
+lib.rlgan_error_string.argtypes = [C.c_int]
+lib.rlgan_error_string.restype = C.c_char_p
+
+
+class RlganError(RuntimeError):
+    pass
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib.rlgan_error_string(rc).decode()
+        raise RlganError(f"{what or 'librlgan_amd'} failed with status {rc}: {msg}")
+
+
+def geometry(kind: int, s_dim: int, a_dim: int) -> Geom:
+    g = Geom()
+    check(lib.rlgan_geometry(kind, s_dim, a_dim, C.byref(g)), "rlgan_geometry")
+    return g
+
+
+def wgrad_chunks(rows: int):
+    cr, nc = C.c_int32(), C.c_int32()
+    check(lib.rlgan_wgrad_chunks(rows, C.byref(cr), C.byref(nc)), "rlgan_wgrad_chunks")
+    return cr.value, nc.value

@@ -1,0 +1,272 @@
+"""The update steps of the reference, expressed as sequences of librlgan_amd kernels.
+
+Sequence per minibatch (Curious_GAN.py:208-213):
+    (1) critic.learn  (2) actor.learn  (3) discriminator.learn  (4) generator.learn
+    (5) discriminator.eval  (6) generator.eval
+(1)->(2) and (3)->(4) are two independent chains, so the fused `update` runs them as two phases,
+{critic, D} then {actor, G}, each phase ending in ONE gradient exchange over a flat bucket.
+
+Data-parallel contract (no counterpart in the reference, which is single-process): every rank holds
+identical weights, computes gradients of its own shard with mean-type losses already divided by the
+GLOBAL batch, the buckets are summed with all_reduce, and every rank applies the same update.  The
+actor's policy gradient is a batch SUM in the reference (DDPG.py:109), so it is summed unscaled.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, lib
+from .core import (NULL_ACTS, NULL_NET, DeviceNet, Workspace, _stream, adam_apply, device, mat, ptr, rmsprop_apply,
+                   rows16, target_update, weight_grads)
+
+
+class GradExchange:
+    """Sum of flat gradient buckets over the data-parallel ranks (RCCL through torch.distributed on
+    GPUs; any initialised backend works, which is how the CPU tests drive it with gloo)."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.group = group
+        self.world = dist.get_world_size(group) if self.enabled else 1
+        self.rank = dist.get_rank(group) if self.enabled else 0
+
+    def all_reduce_sum(self, bucket: torch.Tensor) -> None:
+        if self.enabled:
+            self.dist.all_reduce(bucket, op=self.dist.ReduceOp.SUM, group=self.group)
+
+
+@dataclass
+class ActorState:
+    e: DeviceNet
+    t: DeviceNet
+    lr: float
+    period: int
+    ms: torch.Tensor = None            # A_train RMSProp slot (DDPG.py:112)
+    counter: torch.Tensor = None       # t_replace_counter (DDPG.py:64), device int32
+
+    def __post_init__(self):
+        dev = device()
+        self.ms = torch.ones(self.e.n_params, dtype=torch.float32, device=dev)
+        self.counter = torch.zeros(1, dtype=torch.int32, device=dev)
+
+
+@dataclass
+class CriticState:
+    e: DeviceNet
+    t: DeviceNet
+    lr: float
+    gamma: float
+    period: int
+    trains_actor: bool = True          # minimize() without var_list, DDPG.py:148
+    ms: torch.Tensor = None            # C_train slots for the critic variables
+    ms_actor: torch.Tensor = None      # C_train slots for the actor variables
+    counter: torch.Tensor = None
+
+    def __post_init__(self):
+        dev = device()
+        self.ms = torch.ones(self.e.n_params, dtype=torch.float32, device=dev)
+        self.counter = torch.zeros(1, dtype=torch.int32, device=dev)
+
+    def ensure_actor_slots(self, n: int):
+        if self.ms_actor is None:
+            self.ms_actor = torch.ones(n, dtype=torch.float32, device=device())
+
+
+@dataclass
+class AdamState:
+    net: DeviceNet
+    lr: float
+    m: torch.Tensor = None
+    v: torch.Tensor = None
+    step: torch.Tensor = None          # device int32, t of the Adam bias correction
+
+    def __post_init__(self):
+        dev = device()
+        self.m = torch.zeros(self.net.n_params, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(self.net.n_params, dtype=torch.float32, device=dev)
+        self.step = torch.zeros(1, dtype=torch.int32, device=dev)
+
+
+class StepEngine:
+    """Owns the work arrays (per batch size) and runs the steps.  Stateless w.r.t. the networks."""
+
+    LOSS_CRITIC, LOSS_D_STEP, LOSS_G_STEP, LOSS_D_EVAL, LOSS_G_EVAL = range(5)
+
+    def __init__(self, s_dim: int, a_dim: int, exchange: Optional[GradExchange] = None):
+        self.s_dim, self.a_dim = s_dim, a_dim
+        self.exchange = exchange or GradExchange()
+        self._ws: Dict[Tuple, object] = {}
+        self.losses = torch.zeros(8, dtype=torch.float32, device=device())
+
+    # ---- work arrays ------------------------------------------------------------------------
+    def _get(self, key, make):
+        if key not in self._ws:
+            self._ws[key] = make()
+        return self._ws[key]
+
+    def workspace(self, tag: str, net: DeviceNet, rows: int) -> Workspace:
+        return self._get((tag, net.kind, rows), lambda: Workspace(net, rows))
+
+    def loss_parts(self, tag: str, n: int) -> torch.Tensor:
+        return self._get(("lp", tag, n), lambda: torch.zeros(n, dtype=torch.float32, device=device()))
+
+    def bucket(self, tag: str, n: int) -> torch.Tensor:
+        return self._get(("bucket", tag, n), lambda: torch.zeros(n, dtype=torch.float32, device=device()))
+
+    def _inv_gb(self, n_rows: int) -> float:
+        return 1.0 / float(n_rows * self.exchange.world)
+
+    # ---- (1) critic.learn ---------------------------------------------------------------------
+    def critic_rows(self, C: CriticState, A: ActorState, s, a, r, s_):
+        n = s.shape[0]
+        R = rows16(n)
+        wc = self.workspace("c", C.e, R)
+        wa = self.workspace("ca", A.e, R) if C.trains_actor else None
+        lp = self.loss_parts("c", R // 16)
+        check(lib.rlgan_critic_step_rows(
+            self.s_dim, self.a_dim, C.e.net(True), C.t.net(), A.t.net(), A.e.net(True) if C.trains_actor else NULL_NET,
+            mat(s), mat(a), mat(r), mat(s_), C.gamma, self._inv_gb(n), n,
+            wc.acts(), wa.acts() if wa is not None else NULL_ACTS, lp.data_ptr(), _stream()), "rlgan_critic_step_rows")
+        return wc, wa, lp
+
+    def critic_grads(self, C, A, wc, wa, lp, n):
+        weight_grads(C.e, wc, lp, lp.numel(), self._inv_gb(n), self.losses[self.LOSS_CRITIC:], C.counter)
+        if wa is not None:
+            weight_grads(A.e, wa)
+
+    def critic_apply(self, C: CriticState, A: ActorState, wc, wa):
+        rmsprop_apply(C.e, wc.grad, C.ms, C.lr)
+        if wa is not None:
+            C.ensure_actor_slots(A.e.n_params)
+            rmsprop_apply(A.e, wa.grad, C.ms_actor, C.lr)
+        target_update(C.t, C.e, 1.0, C.counter, C.period)       # hard copy, DDPG.py:176-178
+
+    def critic_step(self, C, A, s, a, r, s_):
+        wc, wa, lp = self.critic_rows(C, A, s, a, r, s_)
+        self.critic_grads(C, A, wc, wa, lp, s.shape[0])
+        self.exchange.all_reduce_sum(wc.grad)
+        if wa is not None:
+            self.exchange.all_reduce_sum(wa.grad)
+        self.critic_apply(C, A, wc, wa)
+        return wc, wa
+
+    # ---- (2) actor.learn ----------------------------------------------------------------------
+    def actor_rows(self, A: ActorState, C: CriticState, s):
+        n = s.shape[0]
+        wa = self.workspace("a", A.e, rows16(n))
+        check(lib.rlgan_actor_step_rows(self.s_dim, self.a_dim, A.e.net(True), C.e.net(True), mat(s), n, wa.acts(),
+                                        _stream()), "rlgan_actor_step_rows")
+        return wa
+
+    def actor_apply(self, A: ActorState, wa):
+        rmsprop_apply(A.e, wa.grad, A.ms, -A.lr)                # RMSPropOptimizer(-lr): ascent, DDPG.py:112
+        target_update(A.t, A.e, 1.0, A.counter, A.period)       # DDPG.py:99-101
+
+    def actor_step(self, A, C, s):
+        wa = self.actor_rows(A, C, s)
+        weight_grads(A.e, wa, counter=A.counter)
+        self.exchange.all_reduce_sum(wa.grad)
+        self.actor_apply(A, wa)
+        return wa
+
+    # ---- (3) discriminator.learn --------------------------------------------------------------
+    def disc_rows(self, D: AdamState, g_data, s_, s, a, smooth: float = 0.0):
+        n = s.shape[0]
+        R = rows16(n)
+        wd = self.workspace("d", D.net, 2 * R)
+        lp = self.loss_parts("d", R // 16)
+        check(lib.rlgan_disc_step_rows(self.s_dim, self.a_dim, D.net.net(True), mat(s), mat(g_data), mat(a), mat(s_),
+                                       1.0 - smooth, self._inv_gb(n), n, wd.acts(), lp.data_ptr(), _stream()),
+              "rlgan_disc_step_rows")
+        return wd, lp
+
+    def disc_step(self, D, g_data, s_, s, a, smooth: float = 0.0):
+        wd, lp = self.disc_rows(D, g_data, s_, s, a, smooth)
+        weight_grads(D.net, wd, lp, lp.numel(), self._inv_gb(s.shape[0]), self.losses[self.LOSS_D_STEP:], D.step)
+        self.exchange.all_reduce_sum(wd.grad)
+        adam_apply(D.net, wd.grad, D.m, D.v, D.step, D.lr)
+        return wd
+
+    # ---- (4) generator.learn ------------------------------------------------------------------
+    def gen_rows(self, G: AdamState, D: AdamState, s, a):
+        n = s.shape[0]
+        R = rows16(n)
+        wg = self.workspace("g", G.net, R)
+        lp = self.loss_parts("g", R // 16)
+        check(lib.rlgan_gen_step_rows(self.s_dim, self.a_dim, G.net.net(True), D.net.net(True), mat(s), mat(a),
+                                      self._inv_gb(n), n, wg.acts(), lp.data_ptr(), _stream()), "rlgan_gen_step_rows")
+        return wg, lp
+
+    def gen_step(self, G, D, s, a):
+        wg, lp = self.gen_rows(G, D, s, a)
+        weight_grads(G.net, wg, lp, lp.numel(), self._inv_gb(s.shape[0]), self.losses[self.LOSS_G_STEP:], G.step)
+        self.exchange.all_reduce_sum(wg.grad)
+        adam_apply(G.net, wg.grad, G.m, G.v, G.step, G.lr)
+        return wg
+
+    # ---- (5)+(6) post-update losses -------------------------------------------------------------
+    def gan_eval(self, G: AdamState, D: AdamState, g_data, s_, s, a, smooth: float = 0.0):
+        """Returns a device tensor [2] = (D_loss, G_loss) of this rank's shard, divided by the global
+        batch (summing over ranks gives the global means)."""
+        n = s.shape[0]
+        nt = rows16(n) // 16
+        lp = self.loss_parts("e", 2 * nt)
+        check(lib.rlgan_gan_eval_rows(self.s_dim, self.a_dim, G.net.net(), D.net.net(), mat(s), mat(g_data), mat(a),
+                                      mat(s_), 1.0 - smooth, n, lp.data_ptr(), _stream()), "rlgan_gan_eval_rows")
+        out = lp.view(2, nt).sum(dim=1) * self._inv_gb(n)
+        self.losses[self.LOSS_D_EVAL:self.LOSS_D_EVAL + 2] = out
+        return out
+
+    # ---- fused update: two phases, one exchange each ------------------------------------------------
+    def update(self, A: ActorState, C: CriticState, G: AdamState, D: AdamState, batch: torch.Tensor,
+               smooth: float = 0.0, with_eval: bool = True, use_curious_reward: bool = True):
+        """One reference update on a [B, 3S+A+2] fp32 batch in the 6-field replay layout
+        (Curious_GAN.py:162,199-213).  Losses land in self.losses (device)."""
+        S, Ad = self.s_dim, self.a_dim
+        n = batch.shape[0]
+        b_s, b_s_, b_g = batch[:, :S], batch[:, S:2 * S], batch[:, 2 * S:3 * S]
+        b_a = batch[:, 3 * S:3 * S + Ad]
+        b_r = batch[:, 3 * S + Ad + (1 if use_curious_reward else 0)]
+        R = rows16(n)
+        nc, na, nd, ng = C.e.n_params, A.e.n_params, D.net.n_params, G.net.n_params
+        # phase 1: critic step and discriminator step
+        wc, wa, lpc = self.critic_rows(C, A, b_s, b_a, b_r, b_s_)
+        wd, lpd = self.disc_rows(D, b_g, b_s_, b_s, b_a, smooth)
+        b1 = self.bucket("p1", nc + na + nd)
+        wc.grad = b1[:nc]
+        if wa is not None:
+            wa.grad = b1[nc:nc + na]
+        wd.grad = b1[nc + na:]
+        self.critic_grads(C, A, wc, wa, lpc, n)
+        weight_grads(D.net, wd, lpd, lpd.numel(), self._inv_gb(n), self.losses[self.LOSS_D_STEP:], D.step)
+        self.exchange.all_reduce_sum(b1)
+        self.critic_apply(C, A, wc, wa)
+        adam_apply(D.net, wd.grad, D.m, D.v, D.step, D.lr)
+        # phase 2: actor step and generator step (both read the nets phase 1 just updated)
+        wa2 = self.actor_rows(A, C, b_s)
+        wg, lpg = self.gen_rows(G, D, b_s, b_a)
+        b2 = self.bucket("p2", na + ng)
+        wa2.grad = b2[:na]
+        wg.grad = b2[na:]
+        weight_grads(A.e, wa2, counter=A.counter)
+        weight_grads(G.net, wg, lpg, lpg.numel(), self._inv_gb(n), self.losses[self.LOSS_G_STEP:], G.step)
+        self.exchange.all_reduce_sum(b2)
+        self.actor_apply(A, wa2)
+        adam_apply(G.net, wg.grad, G.m, G.v, G.step, G.lr)
+        if with_eval:
+            self.gan_eval(G, D, b_g, b_s_, b_s, b_a, smooth)
+
+    def update_ddpg(self, A: ActorState, C: CriticState, batch: torch.Tensor):
+        """`train_DDPG`'s update (Curious_GAN.py:271-281): extrinsic reward column, no G/D."""
+        S, Ad = self.s_dim, self.a_dim
+        b_s, b_s_ = batch[:, :S], batch[:, S:2 * S]
+        b_a, b_r = batch[:, 3 * S:3 * S + Ad], batch[:, 3 * S + Ad]
+        self.critic_step(C, A, b_s, b_a, b_r, b_s_)
+        self.actor_step(A, C, b_s)

@@ -1,0 +1,111 @@
+"""HBM-resident replay ring and the bit-exact index sampler.
+
+The reference keeps a float64 NumPy ring on the host and draws minibatch indices with
+`np.random.choice(capacity, size=n)` from the global legacy stream (Curious_GAN.py:155-169,
+DDPG.py:181-196).  Here the ring is an fp32 device array with 128-byte rows (the networks consume
+float32 either way: TF casts on feed) and the index draw runs on the device on a uploaded copy of
+the MT19937 state, reproducing NumPy's stream bit for bit.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+import torch
+
+from ._lib import check, lib
+from .core import _stream, device
+
+
+class MT19937Device:
+    """Legacy NumPy MT19937 stream living on the device: uint32 key[624] + position."""
+
+    def __init__(self, seed: Optional[int] = None):
+        self.state = torch.zeros(625, dtype=torch.int32, device=device())
+        if seed is not None:
+            self.seed(seed)
+
+    def seed(self, seed: int) -> None:
+        check(lib.rlgan_mt19937_seed(self.state.data_ptr(), int(seed) & 0xFFFFFFFF, _stream()), "rlgan_mt19937_seed")
+
+    def set_numpy_state(self, st) -> None:
+        name, key, pos = st[0], st[1], st[2]
+        assert name == "MT19937"
+        host = np.empty(625, dtype=np.uint32)
+        host[:624] = key
+        host[624] = pos
+        self.state.copy_(torch.from_numpy(host.view(np.int32)))
+
+    def get_numpy_state(self, has_gauss: int = 0, cached: float = 0.0):
+        host = self.state.cpu().numpy().view(np.uint32)
+        return ("MT19937", host[:624].copy(), int(host[624]), has_gauss, cached)
+
+    def choice(self, n_pop: int, n: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Indices of RandomState.choice(n_pop, size=n), int64 on the device."""
+        if out is None:
+            out = torch.empty(n, dtype=torch.int64, device=self.state.device)
+        check(lib.rlgan_mt19937_choice(self.state.data_ptr(), int(n_pop), int(n), out.data_ptr(), _stream()),
+              "rlgan_mt19937_choice")
+        return out
+
+
+class DeviceMemory:
+    """Ring buffer `[capacity, dims]` with the reference's `pointer / capacity / data / sample` API.
+
+    rng: None -> draw indices from NumPy's GLOBAL legacy stream like the reference does (the state is
+    uploaded, advanced on the device and written back, so host code sharing that stream stays in
+    step); or an `MT19937Device` that keeps its own stream on the device (no host traffic).
+    """
+
+    def __init__(self, capacity: int, dims: int, rng: Optional[MT19937Device] = None):
+        self.capacity, self.dims = int(capacity), int(dims)
+        self.ld = max(32, (dims + 31) // 32 * 32)
+        dev = device()
+        self._data = torch.zeros((self.capacity, self.ld), dtype=torch.float32, device=dev)
+        self.pointer = 0
+        self.rng = rng
+        self._global_rng = MT19937Device() if rng is None else None
+        self._stage = torch.zeros((1, self.ld), dtype=torch.float32, device=dev)
+
+    # ---- reference API ------------------------------------------------------------------------
+    @property
+    def data(self) -> np.ndarray:
+        return self._data[:, :self.dims].cpu().numpy().astype(np.float64)
+
+    def store_row(self, row) -> None:
+        row = np.asarray(row, dtype=np.float32).reshape(-1)
+        assert row.size == self.dims
+        self._stage[0, :self.dims].copy_(torch.from_numpy(row))
+        self.store_rows(self._stage[:, :self.dims])
+
+    def store_rows(self, rows: torch.Tensor) -> None:
+        """rows: [n, dims] fp32 device tensor; row i goes to slot (pointer + i) % capacity."""
+        n = rows.shape[0]
+        check(lib.rlgan_replay_store(self._data.data_ptr(), self.capacity, self.dims, self.ld, self.pointer,
+                                     rows.data_ptr(), rows.stride(0), n, _stream()), "rlgan_replay_store")
+        self.pointer += n
+
+    def sample_indices(self, n: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        assert self.pointer >= self.capacity, 'Memory has not been fulfilled'   # Curious_GAN.py:167
+        if self.rng is not None:
+            return self.rng.choice(self.capacity, n, out)
+        st = np.random.get_state()
+        self._global_rng.set_numpy_state(st)
+        idx = self._global_rng.choice(self.capacity, n, out)
+        np.random.set_state(self._global_rng.get_numpy_state(st[3], st[4]))
+        return idx
+
+    def gather(self, idx: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        n = idx.numel()
+        if out is None:
+            out = torch.empty((n, self.dims), dtype=torch.float32, device=self._data.device)
+        check(lib.rlgan_replay_gather(self._data.data_ptr(), self.capacity, self.dims, self.ld, idx.data_ptr(), n,
+                                      out.data_ptr(), out.stride(0), _stream()), "rlgan_replay_gather")
+        return out
+
+    def sample_device(self, n: int) -> torch.Tensor:
+        return self.gather(self.sample_indices(n))
+
+    def sample(self, n: int) -> np.ndarray:
+        """[n, dims] float64 host array, like the reference's `data[indices, :]`."""
+        return self.sample_device(n).cpu().numpy().astype(np.float64)
