@@ -1,0 +1,139 @@
+#!/usr/bin/env python3
+"""Throughput of the RL-GAN hot path on MI355X: learner updates/s and env-steps/s at batch 4096.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N bench.py ...`
+(one rank per GPU, RCCL).  One "step" = one iteration of the training loop of the workload
+`curious_gan_ddpg_arm_b4096`: an acting step of 4096 vectorised arm environments (actor, noise, G,
+env.step, D, intrinsic reward, replay store) followed by one minibatch update at batch 4096 (index
+draw, replay gather, critic/actor/D/G steps and the two post-update losses).  Per-GPU work is
+fixed (weak scaling): every rank owns 4096 environments, a 2^20-row replay ring and a 4096-row
+minibatch; gradients are summed over ranks.  Data are synthetic (random-initialised networks,
+procedurally generated environments); all inputs are resident in HBM before the timed region.
+
+Rank 0 prints one JSON line.  `roofline` describes the dominant kernel (timed live with events on
+the launch stream); `cpu_baseline` is the NumPy float32 restatement of the same update timed on the
+host cores of this box (a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_ENV = 4096
+BATCH = 4096
+CAPACITY = 1 << 20
+
+# algorithmic multiply-accumulates per minibatch row of each kernel (forward + dX chains of the
+# networks it walks; layer shapes 7/9/16 -> 200 -> 200 -> 10/50 -> 2/1/7)
+A, C, G, D = 43420, 43810, 52150, 45210
+MACS_PER_ROW = {
+    "critic_step_rows": 2 * A + 3 * C + 42020,          # a'(s'), q'(s',a'), q(s,a), dX critic, actor fwd, dX actor
+    "actor_step_rows": A + 2 * C + 42020,
+    "disc_step_rows": 2 * (D + 42010),
+    "gen_step_rows": G + 2 * D + 50350,
+    "gan_eval_rows": 3 * D + G,
+}
+PEAK_FP32_TFLOPS = 157.3   # MI355X dense fp32 matrix/vector peak
+
+
+def cpu_baseline(budget_s=12.0):
+    """The oracle's float32 update at batch 4096 on the host cores (NumPy + its BLAS threads)."""
+    import numpy as np
+    from oracle.agent import CuriousAgent
+    ag = CuriousAgent(seed=1234, dtype=np.float32)
+    rng = np.random.RandomState(0)
+    batch = rng.uniform(-1, 1, (BATCH, 25)).astype(np.float32)
+    ag.update(batch)                                   # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        ag.update(batch)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt > budget_s or n >= 200:
+            break
+    threads = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+    return {"value": round(n / dt, 3), "unit": "updates/s", "cores": threads, "kind": "port",
+            "sample": f"{n} float32 NumPy updates at batch {BATCH} (critic, actor, D, G steps + 2 loss evals), {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    import rl_gan_amd as R
+    cfg = R.LearnerConfig(n_env=N_ENV, batch_size=BATCH, memory_capacity=CAPACITY, seed=1)
+    L = R.CuriousLearner(cfg)
+    L.fill()                                            # 257 acting steps: the ring must be full before learning
+    for _ in range(args.warmup):
+        L.step()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        L.step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # per-kernel durations, measured live on the launch stream over a second pass of the same loop
+    L.engine.kernel_events = {}
+    for _ in range(min(args.steps, 50)):
+        L.step()
+    times = L.engine.kernel_times_ms()
+    L.engine.kernel_events = None
+    losses = L.losses()
+
+    if rank == 0:
+        avg_ms = {k: sum(v) / len(v) for k, v in times.items()}
+        dom = max(avg_ms, key=avg_ms.get)
+        flop = 2.0 * MACS_PER_ROW[dom] * BATCH
+        achieved = flop / (avg_ms[dom] * 1e-3) / 1e12
+        out = {
+            "metric": "learner updates/sec (batch 4096)", "value": round(world * args.steps / dt, 2), "unit": "updates/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "curious_gan_ddpg_arm_b4096", "envs_per_gpu": N_ENV, "batch_per_gpu": BATCH,
+                       "replay_rows_per_gpu": CAPACITY, "global_batch": BATCH * world, "parallelism": f"dp{world}"},
+            "env_steps_per_s": round(world * N_ENV * args.steps / dt, 1),
+            "kernel_ms": {k: round(v, 4) for k, v in sorted(avg_ms.items())},
+            "losses": {k: round(v, 6) for k, v in losses.items()},
+            "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 3), "peak": PEAK_FP32_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_TFLOPS, 4), "traffic": None},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -104,6 +104,22 @@ class StepEngine:
         self.exchange = exchange or GradExchange()
         self._ws: Dict[Tuple, object] = {}
         self.losses = torch.zeros(8, dtype=torch.float32, device=device())
+        self.kernel_events = None     # set to {} to record (start, end) event pairs per kernel launch
+
+    def _timed(self, name: str, launch):
+        """Run `launch()`; when kernel_events is a dict, bracket it with events on the launch stream."""
+        if self.kernel_events is None:
+            return launch()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        out = launch()
+        b.record()
+        self.kernel_events.setdefault(name, []).append((a, b))
+        return out
+
+    def kernel_times_ms(self) -> Dict[str, list]:
+        torch.cuda.synchronize()
+        return {k: [a.elapsed_time(b) for a, b in v] for k, v in (self.kernel_events or {}).items()}
 
     # ---- work arrays ------------------------------------------------------------------------
     def _get(self, key, make):
@@ -130,10 +146,10 @@ class StepEngine:
         wc = self.workspace("c", C.e, R)
         wa = self.workspace("ca", A.e, R) if C.trains_actor else None
         lp = self.loss_parts("c", R // 16)
-        check(lib.rlgan_critic_step_rows(
+        self._timed("critic_step_rows", lambda: check(lib.rlgan_critic_step_rows(
             self.s_dim, self.a_dim, C.e.net(True), C.t.net(), A.t.net(), A.e.net(True) if C.trains_actor else NULL_NET,
             mat(s), mat(a), mat(r), mat(s_), C.gamma, self._inv_gb(n), n,
-            wc.acts(), wa.acts() if wa is not None else NULL_ACTS, lp.data_ptr(), _stream()), "rlgan_critic_step_rows")
+            wc.acts(), wa.acts() if wa is not None else NULL_ACTS, lp.data_ptr(), _stream()), "rlgan_critic_step_rows"))
         return wc, wa, lp
 
     def critic_grads(self, C, A, wc, wa, lp, n):
@@ -161,8 +177,8 @@ class StepEngine:
     def actor_rows(self, A: ActorState, C: CriticState, s):
         n = s.shape[0]
         wa = self.workspace("a", A.e, rows16(n))
-        check(lib.rlgan_actor_step_rows(self.s_dim, self.a_dim, A.e.net(True), C.e.net(True), mat(s), n, wa.acts(),
-                                        _stream()), "rlgan_actor_step_rows")
+        self._timed("actor_step_rows", lambda: check(lib.rlgan_actor_step_rows(
+            self.s_dim, self.a_dim, A.e.net(True), C.e.net(True), mat(s), n, wa.acts(), _stream()), "rlgan_actor_step_rows"))
         return wa
 
     def actor_apply(self, A: ActorState, wa):
@@ -182,9 +198,9 @@ class StepEngine:
         R = rows16(n)
         wd = self.workspace("d", D.net, 2 * R)
         lp = self.loss_parts("d", R // 16)
-        check(lib.rlgan_disc_step_rows(self.s_dim, self.a_dim, D.net.net(True), mat(s), mat(g_data), mat(a), mat(s_),
-                                       1.0 - smooth, self._inv_gb(n), n, wd.acts(), lp.data_ptr(), _stream()),
-              "rlgan_disc_step_rows")
+        self._timed("disc_step_rows", lambda: check(lib.rlgan_disc_step_rows(
+            self.s_dim, self.a_dim, D.net.net(True), mat(s), mat(g_data), mat(a), mat(s_),
+            1.0 - smooth, self._inv_gb(n), n, wd.acts(), lp.data_ptr(), _stream()), "rlgan_disc_step_rows"))
         return wd, lp
 
     def disc_step(self, D, g_data, s_, s, a, smooth: float = 0.0):
@@ -200,8 +216,9 @@ class StepEngine:
         R = rows16(n)
         wg = self.workspace("g", G.net, R)
         lp = self.loss_parts("g", R // 16)
-        check(lib.rlgan_gen_step_rows(self.s_dim, self.a_dim, G.net.net(True), D.net.net(True), mat(s), mat(a),
-                                      self._inv_gb(n), n, wg.acts(), lp.data_ptr(), _stream()), "rlgan_gen_step_rows")
+        self._timed("gen_step_rows", lambda: check(lib.rlgan_gen_step_rows(
+            self.s_dim, self.a_dim, G.net.net(True), D.net.net(True), mat(s), mat(a),
+            self._inv_gb(n), n, wg.acts(), lp.data_ptr(), _stream()), "rlgan_gen_step_rows"))
         return wg, lp
 
     def gen_step(self, G, D, s, a):
@@ -218,8 +235,9 @@ class StepEngine:
         n = s.shape[0]
         nt = rows16(n) // 16
         lp = self.loss_parts("e", 2 * nt)
-        check(lib.rlgan_gan_eval_rows(self.s_dim, self.a_dim, G.net.net(), D.net.net(), mat(s), mat(g_data), mat(a),
-                                      mat(s_), 1.0 - smooth, n, lp.data_ptr(), _stream()), "rlgan_gan_eval_rows")
+        self._timed("gan_eval_rows", lambda: check(lib.rlgan_gan_eval_rows(
+            self.s_dim, self.a_dim, G.net.net(), D.net.net(), mat(s), mat(g_data), mat(a),
+            mat(s_), 1.0 - smooth, n, lp.data_ptr(), _stream()), "rlgan_gan_eval_rows"))
         out = lp.view(2, nt).sum(dim=1) * self._inv_gb(n)
         self.losses[self.LOSS_D_EVAL:self.LOSS_D_EVAL + 2] = out
         return out

@@ -113,6 +113,6 @@ def test_soft_target_update_and_tau_one_equals_hard_copy():
     np.testing.assert_allclose(p.C.t.get_flat(), 0.25 * e + 0.75 * t, rtol=1e-6, atol=1e-7)
     target_update(p.C.t, p.C.e, 1.0, None, 1)
     np.testing.assert_array_equal(p.C.t.get_flat(), e)
-    s = torch.rand((16, 7), device="cuda"); a = torch.rand((16, 2), device="cuda")
+    s = torch.rand((16, 7), device="cuda", dtype=torch.float32); a = torch.rand((16, 2), device="cuda", dtype=torch.float32)
     # the fragment image followed the canonical one
     assert torch.equal(mlp_forward(p.C.t, s, a=a), mlp_forward(p.C.e, s, a=a))

@@ -10,8 +10,6 @@ from oracle import nets
 from oracle.agent import CuriousAgent, Hyper
 from oracle.optim import Adam, RMSProp
 
-torch.set_default_dtype(torch.float64)
-
 
 def tparams(p):
     return {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in p.items()}
