@@ -68,6 +68,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--eager", action="store_true", help="launch kernels one by one instead of replaying a HIP graph")
     args = ap.parse_args()
 
     import torch
@@ -84,6 +85,8 @@ def main():
     cfg = R.LearnerConfig(n_env=N_ENV, batch_size=BATCH, memory_capacity=CAPACITY, seed=1)
     L = R.CuriousLearner(cfg)
     L.fill()                                            # 257 acting steps: the ring must be full before learning
+    if not args.eager:
+        L.capture()                                     # one iteration = one HIP graph replay
     for _ in range(args.warmup):
         L.step()
 
@@ -103,7 +106,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # per-kernel durations, measured live on the launch stream over a second pass of the same loop
+    # per-kernel durations, measured live on the launch stream over a second, eager pass of the same loop
+    L._graph = None
     L.engine.kernel_events = {}
     for _ in range(min(args.steps, 50)):
         L.step()

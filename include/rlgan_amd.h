@@ -182,9 +182,12 @@ int rlgan_env_reset(rlgan_env_t env, int n_env, int mode_hard, const uint8_t* ma
 
 /* Episode cut of the rollout loop (Curious_GAN.py:180,222-234): environment i is reset when
  * done[i] != 0 or ep_t[i] >= max_ep_steps-1 (then ep_t[i] = 0 and its new state goes to
- * state_f32[i,:]), otherwise ep_t[i] += 1.  n_resets (optional) counts resets. */
+ * state_f32[i,:]), otherwise ep_t[i] += 1.  n_resets (optional) counts resets.  counters
+ * (optional, device int64[2]) is advanced by the same launch: [0] += n_env (the replay pointer the
+ * acting step reads), [1] += 1 (vector steps taken), which lets a captured graph replay the loop. */
 int rlgan_env_autoreset(rlgan_env_t env, int n_env, int mode_hard, const uint8_t* done, int32_t* ep_t,
-                        int max_ep_steps, const double* u, float* state_f32, int32_t* n_resets, void* stream);
+                        int max_ep_steps, const double* u, float* state_f32, int32_t* n_resets,
+                        int64_t* counters, void* stream);
 
 /* ---- replay ring ----------------------------------------------------------------------------
  * Memory.store_transition Curious_GAN.py:161-165 / DDPG.py:187-191 for n rows at once:
@@ -203,19 +206,23 @@ int rlgan_mt19937_choice(uint32_t* state, int64_t n_pop, int n, int64_t* out_idx
 
 /* Philox4x32-10 draws for order-independent exploration noise and goal placement (no reference
  * counterpart: the reference draws both from the global MT19937, Curious_GAN.py:191, arm_env.py:66).
- * element i of `out` pairs: counter (index0+i), stream id `stream_id`, key `seed`. */
-int rlgan_philox_normal(float* out, int n_pairs, uint64_t seed, uint32_t stream_id, uint64_t index0, void* stream);
-int rlgan_philox_uniform(double* out, int n_pairs, uint64_t seed, uint32_t stream_id, uint64_t index0, void* stream);
+ * element i of `out` pairs: counter (index0+i), stream id `stream_id`, key `seed`.  When `step` (device
+ * int64) is non-NULL, step[0]*step_mul is added to index0 on the device. */
+int rlgan_philox_normal(float* out, int n_pairs, uint64_t seed, uint32_t stream_id, uint64_t index0,
+                        const int64_t* step, int64_t step_mul, void* stream);
+int rlgan_philox_uniform(double* out, int n_pairs, uint64_t seed, uint32_t stream_id, uint64_t index0,
+                         const int64_t* step, int64_t step_mul, void* stream);
 
 /* ---- fused acting path for n_env environments (Curious_GAN.py:190-195) ------------------------
  * a = clip(actor(s) + var*noise, -1, 1); g = G(s, a); (s', r, done) = env.step(a);
  * curious_r = r + ita*(1 - D(s, a, g)); row = [s, s', g, a, r, curious_r] -> replay ring at
  * (pointer + env index) % capacity; s' is written back to state_f32 (the next step's input).
- * noise: [n,2] standard normal fp32 (NULL: no noise).  var is read from device memory. */
+ * noise: [n,2] standard normal fp32 (NULL: no noise).  var is read from device memory.  When
+ * pointer_dev (device int64) is non-NULL the ring position is read from it instead of `pointer`. */
 int rlgan_act_rows(int s_dim, int a_dim, rlgan_net_t actor_eval, rlgan_net_t gen, rlgan_net_t disc,
                    rlgan_env_t env, int n_env, float* state_f32, const float* noise, const float* var,
                    float ita, float* replay, int capacity, int dims, int ld_replay, int64_t pointer,
-                   double* reward_out, uint8_t* done_out, void* stream);
+                   const int64_t* pointer_dev, double* reward_out, uint8_t* done_out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -70,14 +70,14 @@ PROTOTYPES = {
     "rlgan_target_update": [_vp, _vp, _i, _f, _vp, _i, _vp, _vp, _vp],
     "rlgan_env_step": [Env, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "rlgan_env_reset": [Env, _i, _i, _vp, _vp, _vp, _vp, _vp],
-    "rlgan_env_autoreset": [Env, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp],
+    "rlgan_env_autoreset": [Env, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp],
     "rlgan_replay_store": [_vp, _i, _i, _i, _i64, _vp, _i, _i, _vp],
     "rlgan_replay_gather": [_vp, _i, _i, _i, _vp, _i, _vp, _i, _vp],
     "rlgan_mt19937_seed": [_vp, _u32, _vp],
     "rlgan_mt19937_choice": [_vp, _i64, _i, _vp, _vp],
-    "rlgan_philox_normal": [_vp, _i, _u64, _u32, _u64, _vp],
-    "rlgan_philox_uniform": [_vp, _i, _u64, _u32, _u64, _vp],
-    "rlgan_act_rows": [_i, _i, Net, Net, Net, Env, _i, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _i64, _vp, _vp, _vp],
+    "rlgan_philox_normal": [_vp, _i, _u64, _u32, _u64, _vp, _i64, _vp],
+    "rlgan_philox_uniform": [_vp, _i, _u64, _u32, _u64, _vp, _i64, _vp],
+    "rlgan_act_rows": [_i, _i, Net, Net, Net, Env, _i, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _i64, _vp, _vp, _vp, _vp],
 }
 
 for _name, _args in PROTOTYPES.items():

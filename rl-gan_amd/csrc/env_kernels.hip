@@ -119,8 +119,10 @@ __global__ void env_reset_kernel(EnvP E, int n, int mode_hard, const uint8_t* ma
 
 // episode cut `t == MAX_EP_STEPS-1 or done` then `env.reset()` (Curious_GAN.py:180,222-234)
 __global__ void env_autoreset_kernel(EnvP E, int n, int mode_hard, const uint8_t* done, int32_t* ep_t,
-                                     int max_ep_steps, const double* u, float* sof, int32_t* n_resets) {
+                                     int max_ep_steps, const double* u, float* sof, int32_t* n_resets,
+                                     long long* counters) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0 && counters) { counters[0] += n; counters[1] += 1; }   // replay pointer, vector-step count
   if (i >= n) return;
   const int t = ep_t[i];
   if (done[i] || t >= max_ep_steps - 1) {
@@ -148,7 +150,7 @@ struct ActArgs {
   const float* noise;    // [n,2] standard normal or null
   const float* var;      // device scalar
   float ita;
-  float* replay; int capacity, dims, ld_replay; long long pointer;
+  float* replay; int capacity, dims, ld_replay; long long pointer; const long long* pointer_dev;
   double* reward_out; uint8_t* done_out;
 };
 
@@ -213,6 +215,7 @@ __global__ __launch_bounds__(THREADS) void act_kernel(const ActArgs A) {
     rbuf[threadIdx.x * 2 + 1] = rbuf[threadIdx.x * 2] + A.ita * (1.f - sigmoid_f(t.out[threadIdx.x * LD_O]));
   __syncthreads();
   // M.store_transition(s, s_, g, a, r, curious_r)  (Curious_GAN.py:161-165,195)
+  const long long ptr0 = A.pointer_dev ? A.pointer_dev[0] : A.pointer;
   for (int e = threadIdx.x; e < ROWS * 32; e += THREADS) {
     const int rr = e >> 5, cc = e & 31;
     const int i = row0 + rr;
@@ -223,7 +226,7 @@ __global__ __launch_bounds__(THREADS) void act_kernel(const ActArgs A) {
     else if (cc < 3 * S) v = gbuf[rr * 16 + cc - 2 * S];
     else if (cc < 3 * S + Ad) v = abuf[rr * 16 + cc - 3 * S];
     else v = rbuf[rr * 2 + (cc - 3 * S - Ad)];
-    const long long slot = (A.pointer + i) % A.capacity;
+    const long long slot = (ptr0 + i) % A.capacity;
     A.replay[(size_t)slot * A.ld_replay + cc] = v;
     if (cc < S) A.state[(size_t)i * S + cc] = nbuf[rr * 16 + cc];
   }
@@ -254,17 +257,18 @@ int rlgan_env_reset(rlgan_env_t env, int n_env, int mode_hard, const uint8_t* ma
 }
 
 int rlgan_env_autoreset(rlgan_env_t env, int n_env, int mode_hard, const uint8_t* done, int32_t* ep_t,
-                        int max_ep_steps, const double* u, float* state_f32, int32_t* n_resets, void* stream) {
+                        int max_ep_steps, const double* u, float* state_f32, int32_t* n_resets,
+                        int64_t* counters, void* stream) {
   if (!env_ok(env) || n_env <= 0 || !u || !done || !ep_t || !state_f32 || max_ep_steps <= 0) return RLGAN_E_ARG;
   hipLaunchKernelGGL(env_autoreset_kernel, dim3(cdiv(n_env, 256)), dim3(256), 0, (hipStream_t)stream,
-                     EP(env), n_env, mode_hard, done, ep_t, max_ep_steps, u, state_f32, n_resets);
+                     EP(env), n_env, mode_hard, done, ep_t, max_ep_steps, u, state_f32, n_resets, (long long*)counters);
   return launched();
 }
 
 int rlgan_act_rows(int s_dim, int a_dim, rlgan_net_t actor_eval, rlgan_net_t gen, rlgan_net_t disc,
                    rlgan_env_t env, int n_env, float* state_f32, const float* noise, const float* var,
                    float ita, float* replay, int capacity, int dims, int ld_replay, int64_t pointer,
-                   double* reward_out, uint8_t* done_out, void* stream) {
+                   const int64_t* pointer_dev, double* reward_out, uint8_t* done_out, void* stream) {
   ActArgs A;
   if (!make_geo(NET_ACTOR, s_dim, a_dim, A.ga) || !make_geo(NET_GEN, s_dim, a_dim, A.gg) ||
       !make_geo(NET_DISC, s_dim, a_dim, A.gd) || s_dim != 7 || a_dim != 2) return RLGAN_E_DIMS;
@@ -273,7 +277,7 @@ int rlgan_act_rows(int s_dim, int a_dim, rlgan_net_t actor_eval, rlgan_net_t gen
   if (dims != 3 * s_dim + a_dim + 2 || ld_replay < dims || dims > 32 || n_env > capacity) return RLGAN_E_ALIGN;
   A.actor = NetP{actor_eval.wf, nullptr}; A.gen = NetP{gen.wf, nullptr}; A.disc = NetP{disc.wf, nullptr};
   A.env = EP(env); A.n_env = n_env; A.state = state_f32; A.noise = noise; A.var = var; A.ita = ita;
-  A.replay = replay; A.capacity = capacity; A.dims = dims; A.ld_replay = ld_replay; A.pointer = pointer;
+  A.replay = replay; A.capacity = capacity; A.dims = dims; A.ld_replay = ld_replay; A.pointer = pointer; A.pointer_dev = (const long long*)pointer_dev;
   A.reward_out = reward_out; A.done_out = done_out;
   hipLaunchKernelGGL(act_kernel, dim3(cdiv(n_env, ROWS)), dim3(THREADS), 0, (hipStream_t)stream, A);
   return launched();

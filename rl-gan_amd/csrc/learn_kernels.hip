@@ -364,37 +364,92 @@ struct WArgs {
   float* gslabs;
 };
 
+// acc[i] += X[rows r0..r1, strip]^T * dZ[rows r0..r1, tile i], i < T: `xp` / `zp` are this lane's
+// operand addresses for row 0 (consecutive tiles 16 floats apart).  Operands of PIPE 4-row steps are
+// kept in flight; the loop body is branch-free (surplus steps multiply a zero by a re-read row).
+template <int T>
+__device__ __forceinline__ void wgrad_pipe(f32x4 (&acc)[T], const float* __restrict__ xp, int ldx,
+                                           const float* __restrict__ zp, int ldz, int r0, int r1) {
+  const int n = (r1 - r0) >> 2;
+  if (n <= 0) return;
+  const int nblk = (n + PIPE - 1) / PIPE;
+  const int last = r1 - 4;
+  float a[PIPE], b[PIPE][T];
+#pragma unroll
+  for (int j = 0; j < PIPE; ++j) {
+    const int r = r0 + 4 * j, rc = min(r, last);
+    const float av = xp[(size_t)rc * ldx];
+    a[j] = r < r1 ? av : 0.f;
+#pragma unroll
+    for (int i = 0; i < T; ++i) b[j][i] = zp[(size_t)rc * ldz + 16 * i];
+  }
+  for (int blk = 1; blk < nblk; ++blk) {
+#pragma unroll
+    for (int j = 0; j < PIPE; ++j) {
+#pragma unroll
+      for (int i = 0; i < T; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j][i], acc[i], 0, 0, 0);
+      const int r = r0 + 4 * (blk * PIPE + j), rc = min(r, last);
+      const float av = xp[(size_t)rc * ldx];
+      a[j] = r < r1 ? av : 0.f;
+#pragma unroll
+      for (int i = 0; i < T; ++i) b[j][i] = zp[(size_t)rc * ldz + 16 * i];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < PIPE; ++j) {
+#pragma unroll
+    for (int i = 0; i < T; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j][i], acc[i], 0, 0, 0);
+  }
+}
+
+// One workgroup = one 16-row strip of dW for one batch chunk.  4*(NT/4) column tiles are dealt to
+// the four waves (each walks all rows of the chunk); the NT%4 left-over tiles are computed by all
+// four waves together, each taking a quarter of the rows, and summed through LDS in wave order.
 template <int NT>
 __device__ __forceinline__ void wpass_body(const WItem& it, int strip, int chunk, const WArgs& A, float* part) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int TPW = NT / 4, REM = NT % 4, LDP = REM * 16 + 4;
+  const int lane = threadIdx.x & 63, wave = wave_id();
   const int rb = chunk * A.chunk_rows;
   const int re = min(A.rows, rb + A.chunk_rows);
-  const int rpw = A.chunk_rows >> 2;
-  const int w0 = rb + wave * rpw;
-  const int w1 = min(re, w0 + rpw);
-  f32x4 acc[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   const float* xp = it.X + (size_t)(lane >> 4) * it.ldx + 16 * strip + (lane & 15);
   const float* zp = it.dZ + (size_t)(lane >> 4) * it.ldz + (lane & 15);
-  for (int r = w0; r < w1; r += 4) {
-    const float a = xp[(size_t)r * it.ldx];
-    float b[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) b[t] = zp[(size_t)r * it.ldz + 16 * t];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[t], acc[t], 0, 0, 0);
-  }
-  constexpr int LDP = NT * 16 + 4;
-  float* pw = part + wave * ROWS * LDP + ((lane >> 4) * 4) * LDP + (lane & 15);
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) pw[i * LDP + 16 * t] = acc[t][i];
-  }
-  __syncthreads();
   float* gout = A.gslabs + (size_t)chunk * A.gstride + it.goff + (size_t)(16 * strip) * it.np;
-  reduce_epilogue<NT>(part, [=](int r, int c, float z) { gout[r * (NT * 16) + c] = z; });
+  if constexpr (REM > 0) {
+    const int rpw = A.chunk_rows >> 2;
+    const int w0 = rb + wave * rpw, w1 = min(re, w0 + rpw);
+    f32x4 accr[REM];
+#pragma unroll
+    for (int i = 0; i < REM; ++i) accr[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    wgrad_pipe<REM>(accr, xp, it.ldx, zp + 16 * (4 * TPW), it.ldz, w0, w1);
+    float* pw = part + wave * ROWS * LDP + ((lane >> 4) * 4) * LDP + (lane & 15);
+#pragma unroll
+    for (int i = 0; i < REM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pw[r * LDP + 16 * i] = accr[i][r];
+    }
+  }
+  if constexpr (TPW > 0) {
+    f32x4 acc[TPW];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    wgrad_pipe<TPW>(acc, xp, it.ldx, zp + 16 * (wave * TPW), it.ldz, rb, re);
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+      const int col = 16 * (wave * TPW + i) + (lane & 15);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) gout[((lane >> 4) * 4 + r) * (NT * 16) + col] = acc[i][r];
+    }
+  }
+  if constexpr (REM > 0) {
+    __syncthreads();
+    const int row = threadIdx.x >> 4, col = threadIdx.x & 15;
+    constexpr int WS = ROWS * LDP;
+#pragma unroll
+    for (int i = 0; i < REM; ++i) {
+      const float* p = part + row * LDP + 16 * i + col;
+      gout[row * (NT * 16) + 16 * (4 * TPW + i) + col] = ((p[0] + p[WS]) + p[2 * WS]) + p[3 * WS];
+    }
+  }
 }
 
 __global__ __launch_bounds__(THREADS) void wpass_kernel(const WArgs A) {
@@ -402,8 +457,18 @@ __global__ __launch_bounds__(THREADS) void wpass_kernel(const WArgs A) {
   int item = 0;
 #pragma unroll
   for (int i = 1; i < 4; ++i) if ((int)blockIdx.x >= A.blk0[i]) item = i;
-  const WItem& it = A.it[item];
   const int local = blockIdx.x - A.blk0[item];
+  // the item record is copied field by field so that it stays in scalar registers
+  WItem it;
+  it.X = A.it[0].X; it.dZ = A.it[0].dZ; it.ldx = A.it[0].ldx; it.ldz = A.it[0].ldz;
+  it.nstrips = A.it[0].nstrips; it.nt = A.it[0].nt; it.goff = A.it[0].goff; it.np = A.it[0].np;
+#pragma unroll
+  for (int i = 1; i < 4; ++i) {
+    if (item == i) {
+      it.X = A.it[i].X; it.dZ = A.it[i].dZ; it.ldx = A.it[i].ldx; it.ldz = A.it[i].ldz;
+      it.nstrips = A.it[i].nstrips; it.nt = A.it[i].nt; it.goff = A.it[i].goff; it.np = A.it[i].np;
+    }
+  }
   const int strip = local % it.nstrips, chunk = local / it.nstrips;
   if (it.nt == NT_H) wpass_body<NT_H>(it, strip, chunk, A, part);
   else if (it.nt == 4) wpass_body<4>(it, strip, chunk, A, part);
@@ -413,24 +478,32 @@ __global__ __launch_bounds__(THREADS) void wpass_kernel(const WArgs A) {
 // ------------------------------------------------------------------------------------------
 // reduction over chunks, optimizers, target update, packing
 // ------------------------------------------------------------------------------------------
+constexpr int MAX_CHUNKS = 16;
 __global__ void grad_reduce_kernel(const float* __restrict__ gslabs, int nchunks, int gstride,
                                    const int32_t* __restrict__ map_g, int n, float* __restrict__ grad,
                                    const float* loss_parts, int n_parts, float loss_scale, float* loss_out,
                                    int32_t* counter) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p < n) {
-    const int off = map_g[p];
+    const float* src = gslabs + map_g[p];
+    float v[MAX_CHUNKS];
+#pragma unroll
+    for (int c = 0; c < MAX_CHUNKS; ++c) v[c] = c < nchunks ? src[(size_t)c * gstride] : 0.f;
     float s = 0.f;
-    for (int c = 0; c < nchunks; ++c) s += gslabs[(size_t)c * gstride + off];
+#pragma unroll
+    for (int c = 0; c < MAX_CHUNKS; ++c) s += v[c];          // chunk order: bitwise reproducible
     grad[p] = s;
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
+  if (blockIdx.x == 0 && threadIdx.x < 64) {
     if (loss_out) {
+      // 64 lanes, each sums a strided share in index order, then a fixed-order lane reduction
       float s = 0.f;
-      for (int i = 0; i < n_parts; ++i) s += loss_parts[i];
-      loss_out[0] = s * loss_scale;
+      for (int i = threadIdx.x; i < n_parts; i += 64) s += loss_parts[i];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+      if (threadIdx.x == 0) loss_out[0] = s * loss_scale;
     }
-    if (counter) counter[0] += 1;
+    if (counter && threadIdx.x == 0) counter[0] += 1;
   }
 }
 
@@ -635,7 +708,7 @@ int rlgan_weight_grads(int kind, int s_dim, int a_dim, rlgan_acts_t acts, int ro
 int rlgan_grad_reduce(const float* gslabs, int n_chunks, int gpad_floats, const int32_t* map_g,
                       int n_params, float* grad, const float* loss_parts, int n_parts,
                       float loss_scale, float* loss_out, int32_t* counter, void* stream) {
-  if (!gslabs || !map_g || !grad || n_params <= 0 || n_chunks <= 0 || (loss_out && !loss_parts)) return RLGAN_E_ARG;
+  if (!gslabs || !map_g || !grad || n_params <= 0 || n_chunks <= 0 || n_chunks > MAX_CHUNKS || (loss_out && !loss_parts)) return RLGAN_E_ARG;
   hipLaunchKernelGGL(grad_reduce_kernel, dim3(cdiv(n_params, 256)), dim3(256), 0, (hipStream_t)stream,
                      gslabs, n_chunks, gpad_floats, map_g, n_params, grad, loss_parts, n_parts, loss_scale,
                      loss_out, counter);

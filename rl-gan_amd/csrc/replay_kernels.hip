@@ -128,9 +128,10 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32
 }
 
 __global__ void philox_normal_kernel(float* out, int n_pairs, unsigned long long seed, uint32_t stream_id,
-                                     unsigned long long index0) {
+                                     unsigned long long index0, const long long* step, long long step_mul) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_pairs) return;
+  if (step) index0 += (unsigned long long)(step[0] * step_mul);
   const unsigned long long idx = index0 + (unsigned long long)i;
   uint32_t c[4] = {(uint32_t)idx, (uint32_t)(idx >> 32), stream_id, 0u};
   philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
@@ -144,9 +145,10 @@ __global__ void philox_normal_kernel(float* out, int n_pairs, unsigned long long
 }
 
 __global__ void philox_uniform_kernel(double* out, int n_pairs, unsigned long long seed, uint32_t stream_id,
-                                      unsigned long long index0) {
+                                      unsigned long long index0, const long long* step, long long step_mul) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_pairs) return;
+  if (step) index0 += (unsigned long long)(step[0] * step_mul);
   const unsigned long long idx = index0 + (unsigned long long)i;
   uint32_t c[4] = {(uint32_t)idx, (uint32_t)(idx >> 32), stream_id, 0u};
   philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
@@ -193,17 +195,21 @@ int rlgan_mt19937_choice(uint32_t* state, int64_t n_pop, int n, int64_t* out_idx
   return launched();
 }
 
-int rlgan_philox_normal(float* out, int n_pairs, uint64_t seed, uint32_t stream_id, uint64_t index0, void* stream) {
+int rlgan_philox_normal(float* out, int n_pairs, uint64_t seed, uint32_t stream_id, uint64_t index0,
+                        const int64_t* step, int64_t step_mul, void* stream) {
   if (!out || n_pairs <= 0) return RLGAN_E_ARG;
   hipLaunchKernelGGL(philox_normal_kernel, dim3(cdiv(n_pairs, 256)), dim3(256), 0, (hipStream_t)stream,
-                     out, n_pairs, (unsigned long long)seed, stream_id, (unsigned long long)index0);
+                     out, n_pairs, (unsigned long long)seed, stream_id, (unsigned long long)index0,
+                     (const long long*)step, (long long)step_mul);
   return launched();
 }
 
-int rlgan_philox_uniform(double* out, int n_pairs, uint64_t seed, uint32_t stream_id, uint64_t index0, void* stream) {
+int rlgan_philox_uniform(double* out, int n_pairs, uint64_t seed, uint32_t stream_id, uint64_t index0,
+                         const int64_t* step, int64_t step_mul, void* stream) {
   if (!out || n_pairs <= 0) return RLGAN_E_ARG;
   hipLaunchKernelGGL(philox_uniform_kernel, dim3(cdiv(n_pairs, 256)), dim3(256), 0, (hipStream_t)stream,
-                     out, n_pairs, (unsigned long long)seed, stream_id, (unsigned long long)index0);
+                     out, n_pairs, (unsigned long long)seed, stream_id, (unsigned long long)index0,
+                     (const long long*)step, (long long)step_mul);
   return launched();
 }
 

@@ -3,11 +3,11 @@
 // Tiling model: a workgroup of 256 threads (4 waves, one per SIMD) owns 16 consecutive
 // minibatch rows and walks a whole network for them.  One dense layer for a 16-row tile is
 //   Z[16, N] = X[16, K+1] * [W ; b]                 (bias folded in as the row of a constant-1 column)
-// done with v_mfma_f32_16x16x4_f32 (exact f32 FMA chains): the K dimension is split across the
-// four waves, every wave holds all N/16 accumulator tiles, the four partial sums meet in LDS and
-// 256 threads apply the epilogue row-major.  X lives in LDS (it is shared by the waves); the
-// weights are streamed straight from L2 into registers as ready-made B fragments (each wave reads
-// a private quarter of them exactly once, so staging them in LDS would only add a round trip).
+// done with v_mfma_f32_16x16x4_f32 (exact f32 FMA chains).  The 16-wide column tiles of a layer are
+// dealt to the four waves; X lives in LDS (it is shared by the waves); the weights are streamed
+// straight from L2 into registers as ready-made B fragments, several k-steps ahead of their use
+// (each wave reads a private share of them exactly once, so staging them in LDS would only add a
+// round trip).  Layers with a single column tile split K over the waves instead.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -114,75 +114,139 @@ template <> struct NetT<NET_GEN>    { static constexpr int A1 = ACT_RELU,  A2 = 
 template <> struct NetT<NET_DISC>   { static constexpr int A1 = ACT_LRELU, A2 = ACT_LRELU, A3 = ACT_LRELU, A4 = ACT_LINEAR, NT3 = 1, L3 = 17; };
 
 // ---------------------------------------------------------------- LDS carve (floats)
-constexpr int PART_FLOATS = 4 * ROWS * (NP_H + 4);   // four waves' partial sums, widest layer
+constexpr int PART_FLOATS = 4 * ROWS * 20;           // four waves' partial sums of one 16-column tile
 constexpr int WIDE_FLOATS = ROWS * LD_W;
 constexpr int T3_FLOATS = ROWS * LD_3W;              // h3 tile (16 or 64 columns)
 constexpr int X0_FLOATS = ROWS * LD_X0;
 constexpr int O_FLOATS = ROWS * LD_O;
+constexpr int PIPE = 8;                              // k-steps of operands kept in flight per wave
 
-// ---------------------------------------------------------------- the MFMA partial product
-// part[wave][16][NT*16+4] <- X[16, 4*steps of this wave] * fragments.  `xs` is an LDS tile with
-// row stride ldx; `wp` points at the layer's fragment image.
-template <int NT>
-__device__ __forceinline__ void mma_partial(const float* __restrict__ wp, int nsteps,
-                                            const float* xs, int ldx, float* part) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int per = (nsteps + 3) >> 2;
-  const int s0 = wave * per;
-  const int s1 = min(nsteps, s0 + per);
-  f32x4 acc[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const float* xrow = xs + (lane & 15) * ldx + (lane >> 4);
-  const float* wl = wp + lane;
-  float bc[NT], bn[NT];
-  if (s0 < s1) {
-#pragma unroll
-    for (int t = 0; t < NT; ++t) bc[t] = wl[(s0 * NT + t) * 64];
+__device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+
+// Cycle stamps for diagnostic builds only (tools/stamp_probe.hip defines RLGAN_STAMP); in the library
+// build STAMP expands to nothing.
+#ifdef RLGAN_STAMP
+__shared__ unsigned long long rl_stamps[4][192];
+__shared__ int rl_nst[4];
+__device__ __forceinline__ void stamp_here(int tag) {
+  __builtin_amdgcn_sched_barrier(0);
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  if ((threadIdx.x & 63) == 0 && blockIdx.x == RLGAN_STAMP) {
+    const int w = threadIdx.x >> 6;
+    const int k = rl_nst[w];
+    if (k < 192) { rl_stamps[w][k] = ((unsigned long long)tag << 48) | (t & 0xFFFFFFFFFFFFull); rl_nst[w] = k + 1; }
   }
-  for (int s = s0; s < s1; ++s) {
-    const bool more = (s + 1 < s1);
-    if (more) {
+}
+#define STAMP(tag) stamp_here(tag)
+#else
+#define STAMP(tag)
+#endif
+
+// Workgroup barrier for LDS hand-offs only: waits for this wave's LDS operations, not for its
+// outstanding global stores (the activations written for the weight-gradient kernel are not read
+// again inside the launch, so nothing here has to wait for them the way __syncthreads() does).
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// ---------------------------------------------------------------- MFMA product, software pipelined
+// acc[i] += X[16, 4*(s0..s1)] * fragment tile i, i < T.  `xrow` is this lane's A-operand address for
+// k-step 0 (LDS), `wl` this lane's B-operand address of tile 0 at k-step 0 (global, L2-resident),
+// consecutive tiles are 64 floats apart, consecutive k-steps `sstride` floats.  Operands of PIPE
+// k-steps are kept in flight.  The loop body is branch-free: the step count is rounded up to a
+// multiple of PIPE and the surplus steps multiply a zero activation by a re-read valid fragment.
+template <int T>
+__device__ __forceinline__ void mma_pipe(f32x4 (&acc)[T], const float* __restrict__ wl, int sstride,
+                                         const float* xrow, int s0, int s1) {
+  const int n = s1 - s0;
+  if (n <= 0) return;
+  const int nblk = (n + PIPE - 1) / PIPE;
+  const int last = s1 - 1;
+  float a[PIPE], b[PIPE][T];
 #pragma unroll
-      for (int t = 0; t < NT; ++t) bn[t] = wl[((s + 1) * NT + t) * 64];
-    }
-    const float a = xrow[4 * s];
+  for (int j = 0; j < PIPE; ++j) {
+    const int s = s0 + j, sc = min(s, last);
+    const float av = xrow[4 * sc];
+    a[j] = s < s1 ? av : 0.f;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bc[t], acc[t], 0, 0, 0);
-    if (more) {
+    for (int i = 0; i < T; ++i) b[j][i] = wl[sc * sstride + i * 64];
+  }
+  for (int blk = 1; blk < nblk; ++blk) {
 #pragma unroll
-      for (int t = 0; t < NT; ++t) bc[t] = bn[t];
+    for (int j = 0; j < PIPE; ++j) {
+#pragma unroll
+      for (int i = 0; i < T; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j][i], acc[i], 0, 0, 0);
+      const int s = s0 + blk * PIPE + j, sc = min(s, last);
+      const float av = xrow[4 * sc];
+      a[j] = s < s1 ? av : 0.f;
+#pragma unroll
+      for (int i = 0; i < T; ++i) b[j][i] = wl[sc * sstride + i * 64];
     }
   }
-  constexpr int LDP = NT * 16 + 4;
-  float* pw = part + wave * ROWS * LDP + ((lane >> 4) * 4) * LDP + (lane & 15);
 #pragma unroll
-  for (int t = 0; t < NT; ++t) {
+  for (int j = 0; j < PIPE; ++j) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) pw[i * LDP + 16 * t] = acc[t][i];
+    for (int i = 0; i < T; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j][i], acc[i], 0, 0, 0);
   }
 }
 
-// sum the four partials in wave order and hand (row, col, z) to the epilogue
-template <int NT, class F>
-__device__ __forceinline__ void reduce_epilogue(const float* part, F f) {
-  constexpr int NP = NT * 16, LDP = NP + 4, WS = ROWS * LDP;
-  for (int e = threadIdx.x; e < ROWS * NP; e += THREADS) {
-    const int row = e / NP, col = e - row * NP;
-    const float* p = part + row * LDP + col;
-    const float z = ((p[0] + p[WS]) + p[2 * WS]) + p[3 * WS];
-    f(row, col, z);
-  }
-}
-
-// one dense layer of a 16-row tile: partial products, barrier, epilogue, barrier
+// One dense layer of a 16-row tile, Z[16, NT*16] = X * fragments, epilogue f(row, col, z) per element.
+// Of the NT column tiles, 4*(NT/4) are dealt to the four waves (NT/4 each, whole K range, epilogue
+// straight from the accumulators); the NT%4 left-over tiles are computed by all four waves together,
+// each taking a quarter of the K range, and their partial sums meet in LDS (`part`) where they are
+// added in wave order.  Ends with a workgroup barrier: afterwards every wave sees what f wrote.
 template <int NT, class F>
 __device__ __forceinline__ void dense16(const float* __restrict__ wp, int nsteps, const float* xs, int ldx,
                                         float* part, F f) {
-  mma_partial<NT>(wp, nsteps, xs, ldx, part);
-  __syncthreads();
-  reduce_epilogue<NT>(part, f);
-  __syncthreads();
+  constexpr int TPW = NT / 4, REM = NT % 4, LDP = REM * 16 + 4;
+  const int lane = threadIdx.x & 63, wave = wave_id();
+  const float* xrow = xs + (lane & 15) * ldx + (lane >> 4);
+  STAMP(1);
+  if constexpr (REM > 0) {
+    const int per = (nsteps + 3) >> 2;
+    const int s0 = wave * per, s1 = min(nsteps, s0 + per);
+    f32x4 accr[REM];
+#pragma unroll
+    for (int i = 0; i < REM; ++i) accr[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    mma_pipe<REM>(accr, wp + (4 * TPW) * 64 + lane, NT * 64, xrow, s0, s1);
+    float* pw = part + wave * ROWS * LDP + ((lane >> 4) * 4) * LDP + (lane & 15);
+#pragma unroll
+    for (int i = 0; i < REM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pw[r * LDP + 16 * i] = accr[i][r];
+    }
+  }
+  STAMP(2);
+  if constexpr (TPW > 0) {
+    f32x4 acc[TPW];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    mma_pipe<TPW>(acc, wp + (wave * TPW) * 64 + lane, NT * 64, xrow, 0, nsteps);
+    STAMP(3);
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+      const int col = 16 * (wave * TPW + i) + (lane & 15);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) f((lane >> 4) * 4 + r, col, acc[i][r]);
+    }
+  }
+  STAMP(4);
+  lds_barrier();
+  STAMP(5);
+  if constexpr (REM > 0) {
+    const int row = threadIdx.x >> 4, col = threadIdx.x & 15;
+    constexpr int WS = ROWS * LDP;
+#pragma unroll
+    for (int i = 0; i < REM; ++i) {
+      const float* p = part + row * LDP + 16 * i + col;
+      f(row, 16 * (4 * TPW + i) + col, ((p[0] + p[WS]) + p[2 * WS]) + p[3 * WS]);
+    }
+    STAMP(6);
+    lds_barrier();
+    STAMP(7);
+  }
 }
 
 // LDS tiles of one network for one 16-row tile

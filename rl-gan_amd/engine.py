@@ -117,6 +117,11 @@ class StepEngine:
         self.kernel_events.setdefault(name, []).append((a, b))
         return out
 
+    def _side_stream(self) -> "torch.cuda.Stream":
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream()
+        return self._side
+
     def kernel_times_ms(self) -> Dict[str, list]:
         torch.cuda.synchronize()
         return {k: [a.elapsed_time(b) for a, b in v] for k, v in (self.kernel_events or {}).items()}
@@ -254,27 +259,35 @@ class StepEngine:
         b_r = batch[:, 3 * S + Ad + (1 if use_curious_reward else 0)]
         R = rows16(n)
         nc, na, nd, ng = C.e.n_params, A.e.n_params, D.net.n_params, G.net.n_params
-        # phase 1: critic step and discriminator step
-        wc, wa, lpc = self.critic_rows(C, A, b_s, b_a, b_r, b_s_)
-        wd, lpd = self.disc_rows(D, b_g, b_s_, b_s, b_a, smooth)
+        cur = torch.cuda.current_stream()
+        side = self._side_stream()
+        # phase 1: critic step (main stream) and discriminator step (side stream) share the CUs
+        side.wait_stream(cur)
         b1 = self.bucket("p1", nc + na + nd)
+        with torch.cuda.stream(side):
+            wd, lpd = self.disc_rows(D, b_g, b_s_, b_s, b_a, smooth)
+            wd.grad = b1[nc + na:]
+            weight_grads(D.net, wd, lpd, lpd.numel(), self._inv_gb(n), self.losses[self.LOSS_D_STEP:], D.step)
+        wc, wa, lpc = self.critic_rows(C, A, b_s, b_a, b_r, b_s_)
         wc.grad = b1[:nc]
         if wa is not None:
             wa.grad = b1[nc:nc + na]
-        wd.grad = b1[nc + na:]
         self.critic_grads(C, A, wc, wa, lpc, n)
-        weight_grads(D.net, wd, lpd, lpd.numel(), self._inv_gb(n), self.losses[self.LOSS_D_STEP:], D.step)
+        cur.wait_stream(side)
         self.exchange.all_reduce_sum(b1)
         self.critic_apply(C, A, wc, wa)
         adam_apply(D.net, wd.grad, D.m, D.v, D.step, D.lr)
         # phase 2: actor step and generator step (both read the nets phase 1 just updated)
-        wa2 = self.actor_rows(A, C, b_s)
-        wg, lpg = self.gen_rows(G, D, b_s, b_a)
+        side.wait_stream(cur)
         b2 = self.bucket("p2", na + ng)
+        with torch.cuda.stream(side):
+            wg, lpg = self.gen_rows(G, D, b_s, b_a)
+            wg.grad = b2[na:]
+            weight_grads(G.net, wg, lpg, lpg.numel(), self._inv_gb(n), self.losses[self.LOSS_G_STEP:], G.step)
+        wa2 = self.actor_rows(A, C, b_s)
         wa2.grad = b2[:na]
-        wg.grad = b2[na:]
         weight_grads(A.e, wa2, counter=A.counter)
-        weight_grads(G.net, wg, lpg, lpg.numel(), self._inv_gb(n), self.losses[self.LOSS_G_STEP:], G.step)
+        cur.wait_stream(side)
         self.exchange.all_reduce_sum(b2)
         self.actor_apply(A, wa2)
         adam_apply(G.net, wg.grad, G.m, G.v, G.step, G.lr)

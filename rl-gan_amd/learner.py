@@ -82,39 +82,45 @@ class CuriousLearner:
         self.idx = torch.zeros(cfg.batch_size, dtype=torch.int64, device=dev)
         self.batch = torch.zeros((cfg.batch_size, 3 * S + A + 2), dtype=torch.float32, device=dev)
         self.philox_seed = (cfg.seed << 20) ^ (rank + 1)
-        self.t = 0           # vector steps taken
+        self.ctr = torch.zeros(2, dtype=torch.int64, device=dev)   # device counters: replay pointer, vector steps
+        self.t = 0           # vector steps taken (host mirror of ctr[1])
         self.updates = 0
         self._graph = None
         self.reset_all()
 
     # ---- environment side ---------------------------------------------------------------------
-    def _uniforms(self, stream_id: int, index0: int) -> torch.Tensor:
-        check(lib.rlgan_philox_uniform(self.u.data_ptr(), self.cfg.n_env, self.philox_seed, stream_id, index0, _stream()),
-              "rlgan_philox_uniform")
-        return self.u
-
     def reset_all(self) -> None:
-        self.env.reset(self._uniforms(1, 0))
+        check(lib.rlgan_philox_uniform(self.u.data_ptr(), self.cfg.n_env, self.philox_seed, 2, 0, None, 0, _stream()),
+              "rlgan_philox_uniform")
+        self.env.reset(self.u)
         self.ep_t.zero_()
 
-    def rollout_step(self, noise: Optional[torch.Tensor] = None) -> None:
-        """One acting step of every environment (Curious_GAN.py:190-195) and the episode cut."""
+    def _rollout_body(self, noise: Optional[torch.Tensor] = None) -> None:
+        """Acting step + episode cut.  Every per-step scalar (replay position, random-stream offset)
+        is read from the device counters `self.ctr`, so the same launches can be replayed as a graph."""
         cfg = self.cfg
         n = cfg.n_env
+        step = self.ctr[1:].data_ptr()
         if noise is None:
-            check(lib.rlgan_philox_normal(self.noise.data_ptr(), n, self.philox_seed, 0, self.t * n, _stream()),
+            check(lib.rlgan_philox_normal(self.noise.data_ptr(), n, self.philox_seed, 0, 0, step, n, _stream()),
                   "rlgan_philox_normal")
             noise = self.noise
         m = self.memory
         check(lib.rlgan_act_rows(cfg.s_dim, cfg.a_dim, self.actor.e.net(), self.gen.net.net(), self.disc.net.net(),
                                  self.env.handle(), n, self.env.state32.data_ptr(), noise.data_ptr(), self.var.data_ptr(),
-                                 cfg.ita, m._data.data_ptr(), m.capacity, m.dims, m.ld, m.pointer,
+                                 cfg.ita, m._data.data_ptr(), m.capacity, m.dims, m.ld, 0, self.ctr.data_ptr(),
                                  self.env.reward.data_ptr(), self.env.done.data_ptr(), _stream()), "rlgan_act_rows")
-        m.pointer += n
-        self.t += 1
+        check(lib.rlgan_philox_uniform(self.u.data_ptr(), n, self.philox_seed, 1, n, step, n, _stream()), "rlgan_philox_uniform")
         check(lib.rlgan_env_autoreset(self.env.handle(), n, 1 if cfg.mode == 'hard' else 0, self.env.done.data_ptr(),
-                                      self.ep_t.data_ptr(), cfg.max_ep_steps, self._uniforms(1, self.t * n).data_ptr(),
-                                      self.env.state32.data_ptr(), self.n_resets.data_ptr(), _stream()), "rlgan_env_autoreset")
+                                      self.ep_t.data_ptr(), cfg.max_ep_steps, self.u.data_ptr(),
+                                      self.env.state32.data_ptr(), self.n_resets.data_ptr(), self.ctr.data_ptr(), _stream()),
+              "rlgan_env_autoreset")
+
+    def rollout_step(self, noise: Optional[torch.Tensor] = None) -> None:
+        """One acting step of every environment (Curious_GAN.py:190-195) and the episode cut."""
+        self._rollout_body(noise)
+        self.memory.pointer += self.cfg.n_env      # host mirror of ctr[0]
+        self.t += 1                                # host mirror of ctr[1]
 
     # ---- learner side -------------------------------------------------------------------------
     def ready(self) -> bool:
@@ -132,8 +138,34 @@ class CuriousLearner:
         self._update_body()
         self.updates += 1
 
+    def capture(self) -> None:
+        """Record one full iteration (acting step + update) as a HIP graph; `step()` then replays it.
+        Needs a full replay ring.  Two eager iterations run first so every work array exists."""
+        assert self.ready(), "fill() the replay ring before capture()"
+        assert self.engine.kernel_events is None
+        cur = torch.cuda.current_stream()
+        s = torch.cuda.Stream()
+        s.wait_stream(cur)
+        with torch.cuda.stream(s):
+            for _ in range(2):
+                self.rollout_step()
+                self.update()
+        cur.wait_stream(s)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._rollout_body()
+            self._update_body()
+        self._graph = g
+
     def step(self) -> None:
         """One iteration of the training loop: act, store, learn when the ring is full."""
+        if self._graph is not None:
+            self._graph.replay()
+            self.memory.pointer += self.cfg.n_env
+            self.t += 1
+            self.updates += 1
+            return
         self.rollout_step()
         if self.ready():
             self.update()

@@ -18,13 +18,13 @@ from oracle.agent import CuriousAgent, Hyper
 RTOL = 1e-5
 
 
-def close(got, ref, rtol=RTOL, what=""):
+def close(got, ref, rtol=RTOL, what="", atol=0.0):
     got = np.asarray(got, dtype=np.float64)
     ref = np.asarray(ref, dtype=np.float64)
     assert got.shape == ref.shape, (what, got.shape, ref.shape)
     scale = np.max(np.abs(ref)) if ref.size else 0.0
     err = np.abs(got - ref)
-    tol = rtol * np.abs(ref) + rtol * scale
+    tol = rtol * np.abs(ref) + rtol * scale + atol
     bad = err > tol
     if bad.any():
         i = np.argmax(err - tol)
@@ -71,14 +71,18 @@ class Pair:
             for k in p:
                 p[k] = p[k].astype(np.float32).astype(np.float64)
 
-    def check_weights(self, what=""):
+    def check_weights(self, what="", adam_steps=1):
+        """Adam divides by sqrt(v): an entry whose gradient is rounding noise still moves by about
+        lr per step, in a direction the noise decides.  Adam-trained weights therefore get an extra
+        absolute allowance of a quarter of lr per step taken; gradients are compared strictly."""
         o = self.o
+        ad = 0.25 * adam_steps
         close(self.A.e.get_flat(), o.flat("actor_e"), what=what + " actor_e")
         close(self.A.t.get_flat(), o.flat("actor_t"), what=what + " actor_t")
         close(self.C.e.get_flat(), o.flat("critic_e"), what=what + " critic_e")
         close(self.C.t.get_flat(), o.flat("critic_t"), what=what + " critic_t")
-        close(self.G.net.get_flat(), o.flat("gen"), what=what + " gen")
-        close(self.D.net.get_flat(), o.flat("disc"), what=what + " disc")
+        close(self.G.net.get_flat(), o.flat("gen"), what=what + " gen", atol=ad * self.hp.lr_g)
+        close(self.D.net.get_flat(), o.flat("disc"), what=what + " disc", atol=ad * self.hp.lr_d)
 
 
 def make_batch(B, seed=0, f32=True):

@@ -35,7 +35,7 @@ def test_fused_acting_step_matches_oracle_sequence():
         rows_ref.append(np.hstack([s, s_, g, a, r[:, None], cr]))
         _lib.check(_lib.lib.rlgan_act_rows(7, 2, p.A.e.net(), p.G.net.net(), p.D.net.net(), env.handle(), n,
                                            env.state32.data_ptr(), torch.from_numpy(z).cuda().data_ptr(), var.data_ptr(), 0.01,
-                                           mem._data.data_ptr(), cap, 25, mem.ld, mem.pointer,
+                                           mem._data.data_ptr(), cap, 25, mem.ld, mem.pointer, None,
                                            env.reward.data_ptr(), env.done.data_ptr(), _stream()))
         mem.pointer += n
         np.testing.assert_array_equal(env.reward.cpu().numpy(), r)

@@ -164,13 +164,13 @@ def test_philox_words_and_draws_match_oracle():
     z = torch.zeros((n, 2), dtype=torch.float32, device="cuda")
     u = torch.zeros((n, 2), dtype=torch.float64, device="cuda")
     seed, i0 = (77 << 32) | 1234, (1 << 33) + 5
-    _lib.check(_lib.lib.rlgan_philox_normal(z.data_ptr(), n, seed, 3, i0, _stream()))
-    _lib.check(_lib.lib.rlgan_philox_uniform(u.data_ptr(), n, seed, 4, i0, _stream()))
+    _lib.check(_lib.lib.rlgan_philox_normal(z.data_ptr(), n, seed, 3, i0, None, 0, _stream()))
+    _lib.check(_lib.lib.rlgan_philox_uniform(u.data_ptr(), n, seed, 4, i0, None, 0, _stream()))
     zr = np.array([philox.normal_pair(i0 + i, 3, seed) for i in range(n)])
     ur = np.array([philox.uniform_pair(i0 + i, 4, seed) for i in range(n)])
     np.testing.assert_array_equal(u.cpu().numpy(), ur)              # integer path: bit-exact
     np.testing.assert_allclose(z.cpu().numpy(), zr, rtol=2e-5, atol=2e-6)   # float32 libm differences only
     big = torch.zeros((1 << 16, 2), dtype=torch.float32, device="cuda")
-    _lib.check(_lib.lib.rlgan_philox_normal(big.data_ptr(), 1 << 16, 9, 0, 0, _stream()))
+    _lib.check(_lib.lib.rlgan_philox_normal(big.data_ptr(), 1 << 16, 9, 0, 0, None, 0, _stream()))
     b = big.cpu().numpy()
     assert np.isfinite(b).all() and abs(b.mean()) < 0.01 and abs(b.std() - 1) < 0.01

@@ -72,7 +72,7 @@ def test_three_fused_updates_track_the_oracle(B):
         close(l[p.eng.LOSS_CRITIC], ref["critic_loss"], what=f"it{it} critic loss")
         close(l[p.eng.LOSS_D_EVAL], ref["D_loss"], what=f"it{it} D_loss")
         close(l[p.eng.LOSS_G_EVAL], ref["G_loss"], what=f"it{it} G_loss")
-        p.check_weights(f"after update {it}")
+        p.check_weights(f"after update {it}", adam_steps=it + 1)
     assert int(p.C.counter.item()) == 3 and int(p.A.counter.item()) == 3 and int(p.D.step.item()) == 3
     # target nets were copied on calls 0 (both) and 2 (actor) / 3 would be next for the critic
     np.testing.assert_array_equal(p.A.t.get_flat(), p.A.e.get_flat())

@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Times each hot-path kernel in isolation at batch 4096 (back-to-back launches of one kernel
+bracketed by events on the launch stream) and prints achieved TFLOP/s against the fp32 peak.
+A development aid; the judged numbers come from bench.py."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import rl_gan_amd as R
+from rl_gan_amd.core import weight_grads
+from bench import MACS_PER_ROW, PEAK_FP32_TFLOPS
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+REP = 50
+
+
+def timeit(fn):
+    for _ in range(5):
+        fn()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    a.record()
+    for _ in range(REP):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / REP * 1e3      # us
+
+
+def main():
+    cfg = R.LearnerConfig(n_env=B, batch_size=B, memory_capacity=max(1 << 16, 4 * B), seed=1)
+    L = R.CuriousLearner(cfg)
+    L.fill()
+    L.update()
+    e, A, C, G, D = L.engine, L.actor, L.critic, L.gen, L.disc
+    bt = L.batch
+    s, s_, g, a, r = bt[:, :7], bt[:, 7:14], bt[:, 14:21], bt[:, 21:23], bt[:, 24]
+    rows = {}
+    rows["critic_step_rows"] = timeit(lambda: e.critic_rows(C, A, s, a, r, s_))
+    rows["actor_step_rows"] = timeit(lambda: e.actor_rows(A, C, s))
+    rows["disc_step_rows"] = timeit(lambda: e.disc_rows(D, g, s_, s, a))
+    rows["gen_step_rows"] = timeit(lambda: e.gen_rows(G, D, s, a))
+    rows["gan_eval_rows"] = timeit(lambda: e.gan_eval(G, D, g, s_, s, a)) - 0.0
+    for k, us in rows.items():
+        tf = 2.0 * MACS_PER_ROW[k] * B / (us * 1e-6) / 1e12
+        print(f"{k:22s} {us:8.1f} us  {tf:6.1f} TFLOP/s  {100 * tf / PEAK_FP32_TFLOPS:5.1f}% of fp32 peak")
+    wc = e.workspace("c", C.e, B)
+    wd = e.workspace("d", D.net, 2 * B)
+    wg = e.workspace("g", G.net, B)
+    for name, net, ws in (("wgrad critic", C.e, wc), ("wgrad disc(2B rows)", D.net, wd), ("wgrad gen", G.net, wg)):
+        us = timeit(lambda: weight_grads(net, ws))
+        tf = 2.0 * net.n_params * ws.rows / (us * 1e-6) / 1e12
+        print(f"{name:22s} {us:8.1f} us  {tf:6.1f} TFLOP/s  (wpass + reduce)")
+    print(f"{'act step (rollout)':22s} {timeit(L.rollout_step):8.1f} us  (philox + act + autoreset)")
+    print(f"{'sample + gather':22s} {timeit(lambda: L.memory.gather(L.memory.sample_indices(B, L.idx), L.batch)):8.1f} us")
+    print(f"{'full update (eager)':22s} {timeit(L.update):8.1f} us")
+    L.capture()
+    print(f"{'full step (graph)':22s} {timeit(L.step):8.1f} us")
+
+
+if __name__ == "__main__":
+    main()
