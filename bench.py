@@ -39,6 +39,8 @@ MACS_PER_ROW = {
     "gen_step_rows": G + 2 * D + 50350,
     "gan_eval_rows": 3 * D + G,
 }
+MACS_PER_ROW["phase1_rows"] = MACS_PER_ROW["critic_step_rows"] + MACS_PER_ROW["disc_step_rows"]   # one launch, both steps
+MACS_PER_ROW["phase2_rows"] = MACS_PER_ROW["actor_step_rows"] + MACS_PER_ROW["gen_step_rows"]
 PEAK_FP32_TFLOPS = 157.3   # MI355X dense fp32 matrix/vector peak
 
 

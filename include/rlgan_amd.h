@@ -16,8 +16,9 @@
  *   canon : flat fp32 vector, tensors in TensorFlow variable-creation order, each row-major
  *           [in, out] (DDPG.py:78-95,153-172; Curious_GAN.py:46-82,112-135);
  *   wf    : "forward fragments" -- per layer the matrix [W ; b] ((K+1) x N, bias as last row) cut
- *           into MFMA 16x16x4 B-operand fragments: float index ((step*NT + tile)*64 + lane) holds
- *           element (k = 4*step + lane/16, n = 16*tile + lane%16), zero outside the matrix;
+ *           into MFMA 16x16x4 B-operand fragments, K in groups of 16, N in tiles of 16: the float4
+ *           at float index ((group*NT + tile)*64 + lane)*4 holds the elements
+ *           (k = 16*group + 4*(lane/16) + m, n = 16*tile + lane%16), m = 0..3; zero outside;
  *   wb    : "backward fragments" -- the same for W^T (N x K, no bias) used for dX = dZ * W^T.
  * `rlgan_build_maps` gives, per canonical parameter, its float offset in wf, wb and in the padded
  * gradient image the weight-gradient kernel writes.
@@ -62,8 +63,9 @@ typedef struct {
 } rlgan_net_t;
 
 /* per-network activation / pre-activation-gradient work arrays written by a *_rows kernel and
- * consumed by rlgan_weight_grads.  Row-major, `rows` rows (a multiple of 16), leading dimensions:
- * x0: 32, h1/h2/dz1/dz2: 208, h3/dz3: geom.ld3, dz4: 16.  All device. */
+ * consumed by rlgan_weight_grads.  `rows` rows (a multiple of 16) of `ld` columns each, stored as
+ * [rows/16][ld][16]: column-major inside every 16-row tile.  ld = 32 for x0, 208 for
+ * h1/h2/dz1/dz2, geom.ld3 for h3/dz3, 16 for dz4.  All device. */
 typedef struct {
   float* x0;  float* h1;  float* h2;  float* h3;
   float* dz1; float* dz2; float* dz3; float* dz4;
@@ -104,28 +106,54 @@ int rlgan_mlp_forward(int kind, int s_dim, int a_dim, rlgan_net_t net,
 /* Critic.learn DDPG.py:141-148,174-175: y = r + gamma*q'(s_, a'(s_)); L = mean (y-q(s,a))^2.
  * When `actor_eval.wf` is non-NULL the gradient is continued into the actor eval net with TanhGrad
  * taken at the fed action (minimize() without var_list, DDPG.py:148) and `acts_actor` is filled. */
-int rlgan_critic_step_rows(int s_dim, int a_dim, rlgan_net_t critic_eval, rlgan_net_t critic_target,
-                           rlgan_net_t actor_target, rlgan_net_t actor_eval,
-                           rlgan_mat_t s, rlgan_mat_t a, rlgan_mat_t r, rlgan_mat_t s_next,
-                           float gamma, float inv_global_batch, int n_rows,
-                           rlgan_acts_t acts_critic, rlgan_acts_t acts_actor,
-                           float* loss_parts, void* stream);
+typedef struct {
+  int32_t s_dim, a_dim, n_rows;
+  rlgan_net_t critic_eval, critic_target, actor_target, actor_eval;
+  rlgan_mat_t s, a, r, s_next;
+  float gamma, inv_global_batch;
+  rlgan_acts_t acts_critic, acts_actor;
+  float* loss_parts;
+} rlgan_critic_step_t;
+int rlgan_critic_step_rows(const rlgan_critic_step_t* step, void* stream);
 
 /* Actor.learn DDPG.py:97-98,107-113 with a_grads = d(sum q)/da (DDPG.py:151): batch-SUM gradient. */
-int rlgan_actor_step_rows(int s_dim, int a_dim, rlgan_net_t actor_eval, rlgan_net_t critic_eval,
-                          rlgan_mat_t s, int n_rows, rlgan_acts_t acts_actor, void* stream);
+typedef struct {
+  int32_t s_dim, a_dim, n_rows;
+  rlgan_net_t actor_eval, critic_eval;
+  rlgan_mat_t s;
+  rlgan_acts_t acts_actor;
+} rlgan_actor_step_t;
+int rlgan_actor_step_rows(const rlgan_actor_step_t* step, void* stream);
 
 /* Discriminator.learn Curious_GAN.py:33-45,84-85.  acts_disc has 2*rows16 rows: fake rows first
  * (x = stored G sample), then real rows (x = s_next).  loss_parts: fake+real CE sum per tile. */
-int rlgan_disc_step_rows(int s_dim, int a_dim, rlgan_net_t disc,
-                         rlgan_mat_t s, rlgan_mat_t g_stored, rlgan_mat_t a, rlgan_mat_t s_next,
-                         float label_real, float inv_global_batch, int n_rows,
-                         rlgan_acts_t acts_disc, float* loss_parts, void* stream);
+typedef struct {
+  int32_t s_dim, a_dim, n_rows;
+  rlgan_net_t disc;
+  rlgan_mat_t s, g_stored, a, s_next;
+  float label_real, inv_global_batch;
+  rlgan_acts_t acts_disc;
+  float* loss_parts;
+} rlgan_disc_step_t;
+int rlgan_disc_step_rows(const rlgan_disc_step_t* step, void* stream);
 
 /* Generator.learn Curious_GAN.py:137-145: L = mean CE(D_logit(s, a, G(s,a)), 1), dX through D. */
-int rlgan_gen_step_rows(int s_dim, int a_dim, rlgan_net_t gen, rlgan_net_t disc,
-                        rlgan_mat_t s, rlgan_mat_t a, float inv_global_batch, int n_rows,
-                        rlgan_acts_t acts_gen, float* loss_parts, void* stream);
+typedef struct {
+  int32_t s_dim, a_dim, n_rows;
+  rlgan_net_t gen, disc;
+  rlgan_mat_t s, a;
+  float inv_global_batch;
+  rlgan_acts_t acts_gen;
+  float* loss_parts;
+} rlgan_gen_step_t;
+int rlgan_gen_step_rows(const rlgan_gen_step_t* step, void* stream);
+
+/* The reference runs critic.learn, actor.learn, discriminator.learn, generator.learn in that order
+ * (Curious_GAN.py:208-211); critic->actor and D->G are independent chains, so {critic, D} and then
+ * {actor, G} can share a launch each (one tile of either step per compute unit at a time).
+ * Same arguments and results as the single-step calls; both steps must have the same n_rows. */
+int rlgan_phase1_rows(const rlgan_critic_step_t* critic, const rlgan_disc_step_t* disc, void* stream);
+int rlgan_phase2_rows(const rlgan_actor_step_t* actor, const rlgan_gen_step_t* gen, void* stream);
 
 /* Discriminator.eval + Generator.eval Curious_GAN.py:94-95,147-148 in one pass.
  * loss_parts: [2][n_tiles] -- D loss sums then G loss sums. */
@@ -133,33 +161,47 @@ int rlgan_gan_eval_rows(int s_dim, int a_dim, rlgan_net_t gen, rlgan_net_t disc,
                         rlgan_mat_t s, rlgan_mat_t g_stored, rlgan_mat_t a, rlgan_mat_t s_next,
                         float label_real, int n_rows, float* loss_parts, void* stream);
 
-/* ---- weight gradients, reduction, optimizers ------------------------------------------------ */
+/* ---- weight gradients, reduction, optimizers ------------------------------------------------
+ * Each call handles up to three (weight gradients) / four (reduce, apply) networks in one launch. */
+
 /* dW_l = X_l^T dZ_l (bias gradient = the row of the constant-one input column) for the four layers
- * of one network, batch rows split into n_chunks chunks; chunk c writes its partial image at
- * gslabs + c*gpad_floats.  `rows` is the row count of the acts arrays (multiple of 16). */
-int rlgan_weight_grads(int kind, int s_dim, int a_dim, rlgan_acts_t acts, int rows,
-                       float* gslabs, void* stream);
+ * of a network, batch rows split into n_chunks chunks (rlgan_wgrad_chunks); chunk c writes its
+ * partial image at gslabs + c*gpad_floats.  `rows` = row count of the acts arrays (multiple of 16). */
+typedef struct { int32_t kind; int32_t rows; rlgan_acts_t acts; float* gslabs; } rlgan_wgrad_job_t;
+int rlgan_weight_grads(const rlgan_wgrad_job_t* jobs, int n_jobs, int s_dim, int a_dim, void* stream);
 
 /* grad[p] = sum_c gslabs[c*gpad_floats + map_g[p]] in chunk order (bitwise reproducible);
  * optional: loss_out[0] = loss_scale * sum(loss_parts[0..n_parts)), counter[0] += 1. */
-int rlgan_grad_reduce(const float* gslabs, int n_chunks, int gpad_floats, const int32_t* map_g,
-                      int n_params, float* grad, const float* loss_parts, int n_parts,
-                      float loss_scale, float* loss_out, int32_t* counter, void* stream);
+typedef struct {
+  const float* gslabs; int32_t n_chunks; int32_t gpad_floats; const int32_t* map_g; int32_t n_params;
+  float* grad; const float* loss_parts; int32_t n_parts; float loss_scale; float* loss_out; int32_t* counter;
+} rlgan_reduce_job_t;
+int rlgan_grad_reduce(const rlgan_reduce_job_t* jobs, int n_jobs, void* stream);
 
-/* tf.train.RMSPropOptimizer (DDPG.py:112,148): ms <- decay*ms+(1-decay)*g^2 (ms starts at 1),
- * w <- w - lr*g/sqrt(ms+eps).  Writes canon and its fragment images. */
-int rlgan_rmsprop_apply(float* canon, const float* grad, float* ms, int n_params,
-                        float lr, float decay, float eps,
-                        const int32_t* map_f, float* wf, const int32_t* map_b, float* wb, void* stream);
+/* One optimizer step per job, writing canon and its fragment images.
+ *  opt 0: tf.train.RMSPropOptimizer (DDPG.py:112,148): ms <- decay*ms+(1-decay)*g^2 (ms = slot0, starts
+ *         at 1, decay = beta1), w <- w - lr*g/sqrt(ms+eps);
+ *  opt 1: tf.train.AdamOptimizer (Curious_GAN.py:45,142): m = slot0, v = slot1, lr_t =
+ *         lr*sqrt(1-b2^t)/(1-b1^t) with t = step[0] (already incremented for this step, e.g. by
+ *         rlgan_grad_reduce), eps outside the sqrt.
+ * When target_canon is non-NULL the job also updates that target network from the new weights:
+ * target <- tau*w + (1-tau)*target when (counter[0]-1) % period == 0 (counter NULL: always); the
+ * reference only has the hard copy, tau = 1 (DDPG.py:99-101,176-178). */
+typedef struct {
+  int32_t opt; int32_t n_params;
+  float* canon; const float* grad; float* slot0; float* slot1;
+  double lr, beta1, beta2; float eps;
+  const int32_t* step;
+  const int32_t* map_f; float* wf; const int32_t* map_b; float* wb;
+  float* target_canon; float* target_wf; float tau; const int32_t* counter; int32_t period;
+} rlgan_apply_job_t;
+int rlgan_apply(const rlgan_apply_job_t* jobs, int n_jobs, void* stream);
 
-/* tf.train.AdamOptimizer (Curious_GAN.py:45,142): lr_t = lr*sqrt(1-b2^t)/(1-b1^t), t = step[0]
- * (already incremented for this step, e.g. by rlgan_grad_reduce); eps outside the sqrt. */
-int rlgan_adam_apply(float* canon, const float* grad, float* m, float* v, int n_params,
-                     double lr, double beta1, double beta2, float eps, const int32_t* step,
-                     const int32_t* map_f, float* wf, const int32_t* map_b, float* wb, void* stream);
+/* out[k] = scale * sum(parts[k*n_parts .. (k+1)*n_parts)), k < n_sums, in a fixed order: turns the
+ * per-tile loss sums of a *_rows call into the loss value (tf.reduce_mean, Curious_GAN.py:33-40). */
+int rlgan_sum_parts(const float* parts, int n_parts, int n_sums, float scale, float* out, void* stream);
 
-/* target <- tau*eval + (1-tau)*target when (counter[0]-1) % period == 0 (counter NULL: always).
- * The reference only has the hard copy, tau = 1 (DDPG.py:99-101,176-178). */
+/* target <- tau*eval + (1-tau)*target when (counter[0]-1) % period == 0 (counter NULL: always). */
 int rlgan_target_update(float* target_canon, const float* eval_canon, int n_params, float tau,
                         const int32_t* counter, int period, const int32_t* map_f, float* target_wf,
                         void* stream);

@@ -37,6 +37,50 @@ class Env(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("theta", "ends", "goal", "grab", "got")]
 
 
+_i32, _fp = C.c_int32, C.c_void_p
+
+
+class CriticStep(C.Structure):
+    _fields_ = [("s_dim", _i32), ("a_dim", _i32), ("n_rows", _i32),
+                ("critic_eval", Net), ("critic_target", Net), ("actor_target", Net), ("actor_eval", Net),
+                ("s", Mat), ("a", Mat), ("r", Mat), ("s_next", Mat),
+                ("gamma", C.c_float), ("inv_global_batch", C.c_float),
+                ("acts_critic", Acts), ("acts_actor", Acts), ("loss_parts", _fp)]
+
+
+class ActorStep(C.Structure):
+    _fields_ = [("s_dim", _i32), ("a_dim", _i32), ("n_rows", _i32), ("actor_eval", Net), ("critic_eval", Net),
+                ("s", Mat), ("acts_actor", Acts)]
+
+
+class DiscStep(C.Structure):
+    _fields_ = [("s_dim", _i32), ("a_dim", _i32), ("n_rows", _i32), ("disc", Net),
+                ("s", Mat), ("g_stored", Mat), ("a", Mat), ("s_next", Mat),
+                ("label_real", C.c_float), ("inv_global_batch", C.c_float), ("acts_disc", Acts), ("loss_parts", _fp)]
+
+
+class GenStep(C.Structure):
+    _fields_ = [("s_dim", _i32), ("a_dim", _i32), ("n_rows", _i32), ("gen", Net), ("disc", Net),
+                ("s", Mat), ("a", Mat), ("inv_global_batch", C.c_float), ("acts_gen", Acts), ("loss_parts", _fp)]
+
+
+class WgradJob(C.Structure):
+    _fields_ = [("kind", _i32), ("rows", _i32), ("acts", Acts), ("gslabs", _fp)]
+
+
+class ReduceJob(C.Structure):
+    _fields_ = [("gslabs", _fp), ("n_chunks", _i32), ("gpad_floats", _i32), ("map_g", _fp), ("n_params", _i32),
+                ("grad", _fp), ("loss_parts", _fp), ("n_parts", _i32), ("loss_scale", C.c_float),
+                ("loss_out", _fp), ("counter", _fp)]
+
+
+class ApplyJob(C.Structure):
+    _fields_ = [("opt", _i32), ("n_params", _i32), ("canon", _fp), ("grad", _fp), ("slot0", _fp), ("slot1", _fp),
+                ("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_float),
+                ("step", _fp), ("map_f", _fp), ("wf", _fp), ("map_b", _fp), ("wb", _fp),
+                ("target_canon", _fp), ("target_wf", _fp), ("tau", C.c_float), ("counter", _fp), ("period", _i32)]
+
+
 def _load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(
@@ -58,15 +102,17 @@ PROTOTYPES = {
     "rlgan_wgrad_chunks": [_i, C.POINTER(C.c_int32), C.POINTER(C.c_int32)],
     "rlgan_pack_weights": [_vp, _i, _vp, _vp, _vp, _vp, _vp],
     "rlgan_mlp_forward": [_i, _i, _i, Net, Mat, Mat, Mat, _vp, _i, _i, _i, _vp],
-    "rlgan_critic_step_rows": [_i, _i, Net, Net, Net, Net, Mat, Mat, Mat, Mat, _f, _f, _i, Acts, Acts, _vp, _vp],
-    "rlgan_actor_step_rows": [_i, _i, Net, Net, Mat, _i, Acts, _vp],
-    "rlgan_disc_step_rows": [_i, _i, Net, Mat, Mat, Mat, Mat, _f, _f, _i, Acts, _vp, _vp],
-    "rlgan_gen_step_rows": [_i, _i, Net, Net, Mat, Mat, _f, _i, Acts, _vp, _vp],
+    "rlgan_critic_step_rows": [C.POINTER(CriticStep), _vp],
+    "rlgan_actor_step_rows": [C.POINTER(ActorStep), _vp],
+    "rlgan_disc_step_rows": [C.POINTER(DiscStep), _vp],
+    "rlgan_gen_step_rows": [C.POINTER(GenStep), _vp],
+    "rlgan_phase1_rows": [C.POINTER(CriticStep), C.POINTER(DiscStep), _vp],
+    "rlgan_phase2_rows": [C.POINTER(ActorStep), C.POINTER(GenStep), _vp],
     "rlgan_gan_eval_rows": [_i, _i, Net, Net, Mat, Mat, Mat, Mat, _f, _i, _vp, _vp],
-    "rlgan_weight_grads": [_i, _i, _i, Acts, _i, _vp, _vp],
-    "rlgan_grad_reduce": [_vp, _i, _i, _vp, _i, _vp, _vp, _i, _f, _vp, _vp, _vp],
-    "rlgan_rmsprop_apply": [_vp, _vp, _vp, _i, _f, _f, _f, _vp, _vp, _vp, _vp, _vp],
-    "rlgan_adam_apply": [_vp, _vp, _vp, _vp, _i, _d, _d, _d, _f, _vp, _vp, _vp, _vp, _vp, _vp],
+    "rlgan_weight_grads": [C.POINTER(WgradJob), _i, _i, _i, _vp],
+    "rlgan_grad_reduce": [C.POINTER(ReduceJob), _i, _vp],
+    "rlgan_apply": [C.POINTER(ApplyJob), _i, _vp],
+    "rlgan_sum_parts": [_vp, _i, _i, _f, _vp, _vp],
     "rlgan_target_update": [_vp, _vp, _i, _f, _vp, _i, _vp, _vp, _vp],
     "rlgan_env_step": [Env, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "rlgan_env_reset": [Env, _i, _i, _vp, _vp, _vp, _vp, _vp],

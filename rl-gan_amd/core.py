@@ -189,27 +189,59 @@ def mlp_forward(net: DeviceNet, s: torch.Tensor, a: Optional[torch.Tensor] = Non
     return out
 
 
+def wgrad_job(net: DeviceNet, ws: Workspace) -> _lib.WgradJob:
+    return _lib.WgradJob(net.kind, ws.rows, ws.acts(), ws.gslabs.data_ptr())
+
+
+def reduce_job(net: DeviceNet, ws: Workspace, loss_parts=None, n_parts=0, loss_scale=0.0, loss_out=None,
+               counter=None) -> _lib.ReduceJob:
+    return _lib.ReduceJob(ws.gslabs.data_ptr(), ws.n_chunks, net.geom.gpad_floats, net.map_g.data_ptr(), net.n_params,
+                          ws.grad.data_ptr(), ptr(loss_parts), n_parts, loss_scale, ptr(loss_out), ptr(counter))
+
+
+def rmsprop_job(net: DeviceNet, grad: torch.Tensor, ms: torch.Tensor, lr: float, decay=0.9, eps=1e-10,
+                target: Optional[DeviceNet] = None, tau: float = 1.0, counter: Optional[torch.Tensor] = None,
+                period: int = 0) -> _lib.ApplyJob:
+    """tf.train.RMSPropOptimizer step (DDPG.py:112,148), optionally followed by the target-net copy."""
+    return _lib.ApplyJob(0, net.n_params, net.canon.data_ptr(), grad.data_ptr(), ms.data_ptr(), None,
+                         lr, decay, 0.0, eps, None, net.map_f.data_ptr(), net.wf.data_ptr(), ptr(net.map_b), ptr(net.wb),
+                         None if target is None else target.canon.data_ptr(),
+                         None if target is None else target.wf.data_ptr(), tau, ptr(counter), period)
+
+
+def adam_job(net: DeviceNet, grad: torch.Tensor, m: torch.Tensor, v: torch.Tensor, step: torch.Tensor, lr: float,
+             beta1=0.9, beta2=0.999, eps=1e-8) -> _lib.ApplyJob:
+    """tf.train.AdamOptimizer step (Curious_GAN.py:45,142)."""
+    return _lib.ApplyJob(1, net.n_params, net.canon.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(),
+                         lr, beta1, beta2, eps, step.data_ptr(), net.map_f.data_ptr(), net.wf.data_ptr(),
+                         ptr(net.map_b), ptr(net.wb), None, None, 1.0, None, 0)
+
+
+def _arr(cls, jobs):
+    return (cls * len(jobs))(*jobs)
+
+
+def launch_wgrads(jobs, s_dim: int, a_dim: int) -> None:
+    check(lib.rlgan_weight_grads(_arr(_lib.WgradJob, jobs), len(jobs), s_dim, a_dim, _stream()), "rlgan_weight_grads")
+
+
+def launch_reduce(jobs) -> None:
+    check(lib.rlgan_grad_reduce(_arr(_lib.ReduceJob, jobs), len(jobs), _stream()), "rlgan_grad_reduce")
+
+
+def launch_apply(jobs) -> None:
+    check(lib.rlgan_apply(_arr(_lib.ApplyJob, jobs), len(jobs), _stream()), "rlgan_apply")
+
+
 def weight_grads(net: DeviceNet, ws: Workspace, loss_parts=None, n_parts=0, loss_scale=0.0, loss_out=None,
                  counter=None) -> None:
     """dW for all layers of `net` from the work arrays, reduced over batch chunks into ws.grad."""
-    check(lib.rlgan_weight_grads(net.kind, net.s_dim, net.a_dim, ws.acts(), ws.rows, ws.gslabs.data_ptr(), _stream()),
-          "rlgan_weight_grads")
-    check(lib.rlgan_grad_reduce(ws.gslabs.data_ptr(), ws.n_chunks, net.geom.gpad_floats, net.map_g.data_ptr(),
-                                net.n_params, ws.grad.data_ptr(), ptr(loss_parts), n_parts, loss_scale, ptr(loss_out),
-                                ptr(counter), _stream()), "rlgan_grad_reduce")
+    launch_wgrads([wgrad_job(net, ws)], net.s_dim, net.a_dim)
+    launch_reduce([reduce_job(net, ws, loss_parts, n_parts, loss_scale, loss_out, counter)])
 
 
-def rmsprop_apply(net: DeviceNet, grad: torch.Tensor, ms: torch.Tensor, lr: float, decay=0.9, eps=1e-10) -> None:
-    check(lib.rlgan_rmsprop_apply(net.canon.data_ptr(), grad.data_ptr(), ms.data_ptr(), net.n_params, lr, decay, eps,
-                                  net.map_f.data_ptr(), net.wf.data_ptr(), ptr(net.map_b), ptr(net.wb), _stream()),
-          "rlgan_rmsprop_apply")
-
-
-def adam_apply(net: DeviceNet, grad: torch.Tensor, m: torch.Tensor, v: torch.Tensor, step: torch.Tensor, lr: float,
-               beta1=0.9, beta2=0.999, eps=1e-8) -> None:
-    check(lib.rlgan_adam_apply(net.canon.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(), net.n_params,
-                               lr, beta1, beta2, eps, step.data_ptr(), net.map_f.data_ptr(), net.wf.data_ptr(),
-                               ptr(net.map_b), ptr(net.wb), _stream()), "rlgan_adam_apply")
+def sum_parts(parts: torch.Tensor, n_parts: int, n_sums: int, scale: float, out: torch.Tensor) -> None:
+    check(lib.rlgan_sum_parts(parts.data_ptr(), n_parts, n_sums, scale, out.data_ptr(), _stream()), "rlgan_sum_parts")
 
 
 def target_update(target: DeviceNet, evalnet: DeviceNet, tau: float, counter: Optional[torch.Tensor], period: int) -> None:

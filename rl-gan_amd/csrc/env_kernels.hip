@@ -174,11 +174,13 @@ __global__ __launch_bounds__(THREADS) void act_kernel(const ActArgs A) {
   const int gr = row0 + r;
   const bool valid = gr < A.n_env;
 
+  Pre<NT_H, 2> p_a; p_a.issue(A.actor.wf + A.ga.offf[0]);
   sbuf[r * 16 + c] = (valid && c < S) ? A.state[(size_t)gr * S + c] : 0.f;
   __syncthreads();
   load_x0(t.x0, row0, A.n_env, MatIn{sbuf, 16, S, 1}, MatIn{nullptr, 0, 0, 0}, MatIn{nullptr, 0, 0, 0}, nullptr);
   __syncthreads();
-  net_forward<NET_ACTOR, false>(A.actor.wf, A.ga, t, none);               // a = actor.choose_action(s)
+  Pre<NT_H, 2> p_g;
+  net_forward<NET_ACTOR, false>(A.actor.wf, A.ga, t, none, p_a, [&] { p_g.issue(A.gen.wf + A.gg.offf[0]); });   // a = actor.choose_action(s)
   // a = clip(normal(a, var), -1, 1) evaluated in float64 like NumPy (Curious_GAN.py:191)
   __shared__ double a64[ROWS * 2];
   if (c < Ad) {
@@ -193,7 +195,8 @@ __global__ __launch_bounds__(THREADS) void act_kernel(const ActArgs A) {
   __syncthreads();
   load_x0(t.x0, row0, A.n_env, MatIn{sbuf, 16, S, 1}, MatIn{abuf, 16, Ad, 1}, MatIn{nullptr, 0, 0, 0}, nullptr);
   __syncthreads();
-  net_forward<NET_GEN, false>(A.gen.wf, A.gg, t, none);                   // g = generator.predict(s, a)
+  Pre<NT_H, 2> p_d;
+  net_forward<NET_GEN, false>(A.gen.wf, A.gg, t, none, p_g, [&] { p_d.issue(A.disc.wf + A.gd.offf[0]); });   // g = generator.predict(s, a)
   gbuf[r * 16 + c] = c < S ? t.out[r * LD_O + c] : 0.f;
   if (threadIdx.x < ROWS) {                                              // s_, r, done = env.step(a)
     const int i = row0 + threadIdx.x;
@@ -210,7 +213,7 @@ __global__ __launch_bounds__(THREADS) void act_kernel(const ActArgs A) {
   __syncthreads();
   load_x0(t.x0, row0, A.n_env, MatIn{sbuf, 16, S, 1}, MatIn{gbuf, 16, S, 1}, MatIn{abuf, 16, Ad, 1}, nullptr);
   __syncthreads();
-  net_forward<NET_DISC, false>(A.disc.wf, A.gd, t, none);
+  net_forward<NET_DISC, false>(A.disc.wf, A.gd, t, none, p_d, NoNext{});
   if (threadIdx.x < ROWS)                                                // curious_r = r + ITA*(1 - D_fake)
     rbuf[threadIdx.x * 2 + 1] = rbuf[threadIdx.x * 2] + A.ita * (1.f - sigmoid_f(t.out[threadIdx.x * LD_O]));
   __syncthreads();

@@ -63,26 +63,29 @@ struct CriticArgs {
   Acts8 acts_c, acts_a;
   float* loss_parts;
 };
+constexpr int CRITIC_LDS = PART_FLOATS + SET_FLOATS + O_FLOATS + 64;
 
-__global__ __launch_bounds__(THREADS) void critic_step_kernel(const CriticArgs A) {
-  __shared__ __attribute__((aligned(16))) float smem[PART_FLOATS + SET_FLOATS + O_FLOATS + 64];
+__device__ __forceinline__ void critic_tile(const CriticArgs& A, float* smem, int tile) {
   float* part = smem;
   TileSet ts = carve_set(smem + PART_FLOATS);
   float* dsave = smem + PART_FLOATS + SET_FLOATS;   // [16][LD_O]
   float* small = dsave + O_FLOATS;                  // y[16], dq[16], scratch[16]
   const Tiles t = mk(ts, part);
-  const int row0 = blockIdx.x * ROWS;
+  const int row0 = tile * ROWS;
   const int S = A.gc.S, Ad = A.gc.A;
   const ActsG none{};
 
   // target action a' = actor_target(s')
+  Pre<NT_H, 2> p_at; p_at.issue(A.actor_t.wf + A.ga.offf[0]);
   load_x0(t.x0, row0, A.n_rows, gin(A.s_next, S), nil(), nil(), nullptr);
   __syncthreads();
-  net_forward<NET_ACTOR, false>(A.actor_t.wf, A.ga, t, none);
+  Pre<NT_H, 2> p_ct;
+  net_forward<NET_ACTOR, false>(A.actor_t.wf, A.ga, t, none, p_at, [&] { p_ct.issue(A.critic_t.wf + A.gc.offf[0]); });
   // q' = critic_target(s', a')
   load_x0(t.x0, row0, A.n_rows, gin(A.s_next, S), lin(t.out, LD_O, Ad), nil(), nullptr);
   __syncthreads();
-  net_forward<NET_CRITIC, false>(A.critic_t.wf, A.gc, t, none);
+  Pre<NT_H, 2> p_ce;
+  net_forward<NET_CRITIC, false>(A.critic_t.wf, A.gc, t, none, p_ct, [&] { p_ce.issue(A.critic_e.wf + A.gc.offf[0]); });
   if (threadIdx.x < ROWS) {
     const int gr = row0 + threadIdx.x;
     const float rew = gr < A.n_rows ? A.r.p[(size_t)gr * A.r.ld] : 0.f;
@@ -92,7 +95,8 @@ __global__ __launch_bounds__(THREADS) void critic_step_kernel(const CriticArgs A
   const ActsG wc = acts_at(A.acts_c.p, row0, A.gc.ld3);
   load_x0(t.x0, row0, A.n_rows, gin(A.s, S), gin(A.a, Ad), nil(), wc.x0);
   __syncthreads();
-  net_forward<NET_CRITIC, true>(A.critic_e.wf, A.gc, t, wc);
+  Pre<1, 1> p_cb;
+  net_forward<NET_CRITIC, true>(A.critic_e.wf, A.gc, t, wc, p_ce, [&] { p_cb.issue(A.critic_e.wb + A.gc.offb[3]); });
   float l = 0.f;
   if (threadIdx.x < ROWS) {
     const bool valid = row0 + threadIdx.x < A.n_rows;
@@ -101,11 +105,12 @@ __global__ __launch_bounds__(THREADS) void critic_step_kernel(const CriticArgs A
     small[16 + threadIdx.x] = valid ? -2.f * diff * A.inv_gb : 0.f;       // d mean((y-q)^2) / dq
   }
   const float lsum = sum16_lds(small + 32, l);
-  if (threadIdx.x == 0) A.loss_parts[blockIdx.x] = lsum;
+  if (threadIdx.x == 0) A.loss_parts[tile] = lsum;
   fill_out_col0(t.out, small + 16);
   __syncthreads();
   if (A.train_actor) {
-    net_backward<NET_CRITIC, true, true>(A.critic_e.wb, A.gc, t, wc);
+    Pre<NT_H, 2> p_ae;
+    net_backward<NET_CRITIC, true, true>(A.critic_e.wb, A.gc, t, wc, p_cb, [&] { p_ae.issue(A.actor_e.wf + A.ga.offf[0]); });
     // gradient continues through the tensor actor.a: TanhGrad at the FED action (DDPG.py:148,175)
     {
       const int r = threadIdx.x >> 4, c = threadIdx.x & 15;
@@ -121,16 +126,22 @@ __global__ __launch_bounds__(THREADS) void critic_step_kernel(const CriticArgs A
     const ActsG wa = acts_at(A.acts_a.p, row0, A.ga.ld3);
     load_x0(t.x0, row0, A.n_rows, gin(A.s, S), nil(), nil(), wa.x0);
     __syncthreads();
-    net_forward<NET_ACTOR, true>(A.actor_e.wf, A.ga, t, wa);
+    Pre<1, 1> p_ab;
+    net_forward<NET_ACTOR, true>(A.actor_e.wf, A.ga, t, wa, p_ae, [&] { p_ab.issue(A.actor_e.wb + A.ga.offb[3]); });
     {
       const int r = threadIdx.x >> 4, c = threadIdx.x & 15;
       t.out[r * LD_O + c] = dsave[r * LD_O + c];
     }
     __syncthreads();
-    net_backward<NET_ACTOR, false, true>(A.actor_e.wb, A.ga, t, wa);
+    net_backward<NET_ACTOR, false, true>(A.actor_e.wb, A.ga, t, wa, p_ab, NoNext{});
   } else {
-    net_backward<NET_CRITIC, false, true>(A.critic_e.wb, A.gc, t, wc);
+    net_backward<NET_CRITIC, false, true>(A.critic_e.wb, A.gc, t, wc, p_cb, NoNext{});
   }
+}
+
+__global__ __launch_bounds__(THREADS) void critic_step_kernel(const CriticArgs A) {
+  __shared__ __attribute__((aligned(16))) float smem[CRITIC_LDS];
+  critic_tile(A, smem, blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -143,30 +154,34 @@ struct ActorArgs {
   int n_rows;
   Acts8 acts_a;
 };
+constexpr int ACTOR_LDS = PART_FLOATS + 2 * SET_FLOATS;
 
-__global__ __launch_bounds__(THREADS) void actor_step_kernel(const ActorArgs A) {
-  __shared__ __attribute__((aligned(16))) float smem[PART_FLOATS + 2 * SET_FLOATS];
+__device__ __forceinline__ void actor_tile(const ActorArgs& A, float* smem, int tile) {
   float* part = smem;
   const TileSet sa = carve_set(smem + PART_FLOATS);
   const TileSet sc = carve_set(smem + PART_FLOATS + SET_FLOATS);
   const Tiles ta = mk(sa, part), tc = mk(sc, part);
-  const int row0 = blockIdx.x * ROWS;
+  const int row0 = tile * ROWS;
   const int S = A.gc.S, Ad = A.gc.A;
   const ActsG none{};
   const ActsG wa = acts_at(A.acts_a.p, row0, A.ga.ld3);
 
+  Pre<NT_H, 2> p_a; p_a.issue(A.actor_e.wf + A.ga.offf[0]);
   load_x0(ta.x0, row0, A.n_rows, gin(A.s, S), nil(), nil(), wa.x0);
   __syncthreads();
-  net_forward<NET_ACTOR, true>(A.actor_e.wf, A.ga, ta, wa);            // a = actor_eval(s), live
+  Pre<NT_H, 2> p_c;
+  net_forward<NET_ACTOR, true>(A.actor_e.wf, A.ga, ta, wa, p_a, [&] { p_c.issue(A.critic_e.wf + A.gc.offf[0]); });   // a = actor_eval(s), live
   load_x0(tc.x0, row0, A.n_rows, gin(A.s, S), lin(ta.out, LD_O, Ad), nil(), nullptr);
   __syncthreads();
-  net_forward<NET_CRITIC, false>(A.critic_e.wf, A.gc, tc, none);
+  Pre<1, 1> p_cb;
+  net_forward<NET_CRITIC, false>(A.critic_e.wf, A.gc, tc, none, p_c, [&] { p_cb.issue(A.critic_e.wb + A.gc.offb[3]); });
   {
     const int r = threadIdx.x >> 4, c = threadIdx.x & 15;
     tc.out[r * LD_O + c] = (c == 0 && row0 + r < A.n_rows) ? 1.f : 0.f;   // d(sum_b q_b)/dq = 1, DDPG.py:151
   }
   __syncthreads();
-  net_backward<NET_CRITIC, true, false>(A.critic_e.wb, A.gc, tc, none);
+  Pre<1, 1> p_ab;
+  net_backward<NET_CRITIC, true, false>(A.critic_e.wb, A.gc, tc, none, p_cb, [&] { p_ab.issue(A.actor_e.wb + A.ga.offb[3]); });
   {
     const int r = threadIdx.x >> 4, c = threadIdx.x & 15;
     float v = 0.f;
@@ -177,7 +192,12 @@ __global__ __launch_bounds__(THREADS) void actor_step_kernel(const ActorArgs A) 
     ta.out[r * LD_O + c] = v;
   }
   __syncthreads();
-  net_backward<NET_ACTOR, false, true>(A.actor_e.wb, A.ga, ta, wa);
+  net_backward<NET_ACTOR, false, true>(A.actor_e.wb, A.ga, ta, wa, p_ab, NoNext{});
+}
+
+__global__ __launch_bounds__(THREADS) void actor_step_kernel(const ActorArgs A) {
+  __shared__ __attribute__((aligned(16))) float smem[ACTOR_LDS];
+  actor_tile(A, smem, blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -192,21 +212,24 @@ struct DiscArgs {
   Acts8 acts_d;
   float* loss_parts;
 };
+constexpr int DISC_LDS = PART_FLOATS + SET_FLOATS + 64;
 
-__global__ __launch_bounds__(THREADS) void disc_step_kernel(const DiscArgs A) {
-  __shared__ __attribute__((aligned(16))) float smem[PART_FLOATS + SET_FLOATS + 64];
+__device__ __forceinline__ void disc_tile(const DiscArgs& A, float* smem, int tile) {
   float* part = smem;
   const TileSet ts = carve_set(smem + PART_FLOATS);
   float* small = smem + PART_FLOATS + SET_FLOATS;
   const Tiles t = mk(ts, part);
-  const int row0 = blockIdx.x * ROWS;
+  const int row0 = tile * ROWS;
   const int S = A.gd.S, Ad = A.gd.A;
   float ltot = 0.f;
+  Pre<NT_H, 2> p_f; p_f.issue(A.disc.wf + A.gd.offf[0]);
+#pragma unroll 1
   for (int pass = 0; pass < 2; ++pass) {
     const ActsG wd = acts_at(A.acts_d.p, pass * A.rows16 + row0, A.gd.ld3);
     load_x0(t.x0, row0, A.n_rows, gin(A.s, S), gin(pass == 0 ? A.g : A.s_next, S), gin(A.a, Ad), wd.x0);
     __syncthreads();
-    net_forward<NET_DISC, true>(A.disc.wf, A.gd, t, wd);
+    Pre<1, 1> p_b;
+    net_forward<NET_DISC, true>(A.disc.wf, A.gd, t, wd, p_f, [&] { p_b.issue(A.disc.wb + A.gd.offb[3]); });
     const float label = pass == 0 ? 0.f : A.label_real;
     float l = 0.f;
     if (threadIdx.x < ROWS) {
@@ -218,9 +241,14 @@ __global__ __launch_bounds__(THREADS) void disc_step_kernel(const DiscArgs A) {
     ltot += sum16_lds(small + 16, l);
     fill_out_col0(t.out, small);
     __syncthreads();
-    net_backward<NET_DISC, false, true>(A.disc.wb, A.gd, t, wd);
+    net_backward<NET_DISC, false, true>(A.disc.wb, A.gd, t, wd, p_b, [&] { p_f.issue(A.disc.wf + A.gd.offf[0]); });
   }
-  if (threadIdx.x == 0) A.loss_parts[blockIdx.x] = ltot;
+  if (threadIdx.x == 0) A.loss_parts[tile] = ltot;
+}
+
+__global__ __launch_bounds__(THREADS) void disc_step_kernel(const DiscArgs A) {
+  __shared__ __attribute__((aligned(16))) float smem[DISC_LDS];
+  disc_tile(A, smem, blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -235,25 +263,28 @@ struct GenArgs {
   Acts8 acts_g;
   float* loss_parts;
 };
+constexpr int GEN_LDS = PART_FLOATS + 2 * SET_FLOATS + 64;
 
-__global__ __launch_bounds__(THREADS) void gen_step_kernel(const GenArgs A) {
-  __shared__ __attribute__((aligned(16))) float smem[PART_FLOATS + 2 * SET_FLOATS + 64];
+__device__ __forceinline__ void gen_tile(const GenArgs& A, float* smem, int tile) {
   float* part = smem;
   const TileSet sg = carve_set(smem + PART_FLOATS);
   const TileSet sd = carve_set(smem + PART_FLOATS + SET_FLOATS);
   float* small = smem + PART_FLOATS + 2 * SET_FLOATS;
   const Tiles tg = mk(sg, part), td = mk(sd, part);
-  const int row0 = blockIdx.x * ROWS;
+  const int row0 = tile * ROWS;
   const int S = A.gg.S, Ad = A.gg.A;
   const ActsG none{};
   const ActsG wg = acts_at(A.acts_g.p, row0, A.gg.ld3);
 
+  Pre<NT_H, 2> p_g; p_g.issue(A.gen.wf + A.gg.offf[0]);
   load_x0(tg.x0, row0, A.n_rows, gin(A.s, S), gin(A.a, Ad), nil(), wg.x0);
   __syncthreads();
-  net_forward<NET_GEN, true>(A.gen.wf, A.gg, tg, wg);                  // g^ = G(s, a), live
+  Pre<NT_H, 2> p_d;
+  net_forward<NET_GEN, true>(A.gen.wf, A.gg, tg, wg, p_g, [&] { p_d.issue(A.disc.wf + A.gd.offf[0]); });   // g^ = G(s, a), live
   load_x0(td.x0, row0, A.n_rows, gin(A.s, S), lin(tg.out, LD_O, S), gin(A.a, Ad), nullptr);
   __syncthreads();
-  net_forward<NET_DISC, false>(A.disc.wf, A.gd, td, none);
+  Pre<1, 1> p_db;
+  net_forward<NET_DISC, false>(A.disc.wf, A.gd, td, none, p_d, [&] { p_db.issue(A.disc.wb + A.gd.offb[3]); });
   float l = 0.f;
   if (threadIdx.x < ROWS) {
     const bool valid = row0 + threadIdx.x < A.n_rows;
@@ -262,16 +293,43 @@ __global__ __launch_bounds__(THREADS) void gen_step_kernel(const GenArgs A) {
     small[threadIdx.x] = valid ? (sigmoid_f(x) - 1.f) * A.inv_gb : 0.f;
   }
   const float lsum = sum16_lds(small + 16, l);
-  if (threadIdx.x == 0) A.loss_parts[blockIdx.x] = lsum;
+  if (threadIdx.x == 0) A.loss_parts[tile] = lsum;
   fill_out_col0(td.out, small);
   __syncthreads();
-  net_backward<NET_DISC, true, false>(A.disc.wb, A.gd, td, none);       // dX only: D is not trained here
+  Pre<4, 1> p_gb;
+  net_backward<NET_DISC, true, false>(A.disc.wb, A.gd, td, none, p_db, [&] { p_gb.issue(A.gen.wb + A.gg.offb[3]); });   // dX only
   {
     const int r = threadIdx.x >> 4, c = threadIdx.x & 15;
     tg.out[r * LD_O + c] = c < S ? td.x0[r * LD_X0 + S + c] : 0.f;      // dL/dg^ (linear output layer)
   }
   __syncthreads();
-  net_backward<NET_GEN, false, true>(A.gen.wb, A.gg, tg, wg);
+  net_backward<NET_GEN, false, true>(A.gen.wb, A.gg, tg, wg, p_gb, NoNext{});
+}
+
+__global__ __launch_bounds__(THREADS) void gen_step_kernel(const GenArgs A) {
+  __shared__ __attribute__((aligned(16))) float smem[GEN_LDS];
+  gen_tile(A, smem, blockIdx.x);
+}
+
+// ------------------------------------------------------------------------------------------
+// fused phases: two independent steps share one launch so that every CU holds a tile of each
+// ------------------------------------------------------------------------------------------
+constexpr int PHASE1_LDS = CRITIC_LDS > DISC_LDS ? CRITIC_LDS : DISC_LDS;
+constexpr int PHASE2_LDS = ACTOR_LDS > GEN_LDS ? ACTOR_LDS : GEN_LDS;
+
+// even workgroups walk critic tiles, odd ones discriminator tiles (both steps have the same tile count)
+__global__ __launch_bounds__(THREADS) void phase1_kernel(const CriticArgs C, const DiscArgs D) {
+  __shared__ __attribute__((aligned(16))) float smem[PHASE1_LDS];
+  const int tile = blockIdx.x >> 1;
+  if (blockIdx.x & 1) disc_tile(D, smem, tile);
+  else critic_tile(C, smem, tile);
+}
+
+__global__ __launch_bounds__(THREADS) void phase2_kernel(const ActorArgs Aa, const GenArgs G) {
+  __shared__ __attribute__((aligned(16))) float smem[PHASE2_LDS];
+  const int tile = blockIdx.x >> 1;
+  if (blockIdx.x & 1) gen_tile(G, smem, tile);
+  else actor_tile(Aa, smem, tile);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -296,22 +354,24 @@ __global__ __launch_bounds__(THREADS) void gan_eval_kernel(const EvalArgs A) {
   const int row0 = blockIdx.x * ROWS;
   const int S = A.gg.S, Ad = A.gg.A;
   const ActsG none{};
-  float ld = 0.f;
-  for (int pass = 0; pass < 2; ++pass) {
-    load_x0(td.x0, row0, A.n_rows, gin(A.s, S), gin(pass == 0 ? A.g : A.s_next, S), gin(A.a, Ad), nullptr);
+  Pre<NT_H, 2> p_d; p_d.issue(A.disc.wf + A.gd.offf[0]);
+  Pre<NT_H, 2> p_g;
+  auto d_loss = [&](const MatIn& xin, float label, auto next) -> float {
+    load_x0(td.x0, row0, A.n_rows, gin(A.s, S), xin, gin(A.a, Ad), nullptr);
     __syncthreads();
-    net_forward<NET_DISC, false>(A.disc.wf, A.gd, td, none);
+    net_forward<NET_DISC, false>(A.disc.wf, A.gd, td, none, p_d, next);
     float l = 0.f;
-    if (threadIdx.x < ROWS && row0 + threadIdx.x < A.n_rows)
-      l = sigmoid_ce(td.out[threadIdx.x * LD_O], pass == 0 ? 0.f : A.label_real);
-    ld += sum16_lds(small, l);
-  }
+    if (threadIdx.x < ROWS && row0 + threadIdx.x < A.n_rows) l = sigmoid_ce(td.out[threadIdx.x * LD_O], label);
+    return sum16_lds(small, l);
+  };
+  float ld = d_loss(gin(A.g, S), 0.f, [&] { p_d.issue(A.disc.wf + A.gd.offf[0]); });
+  ld += d_loss(gin(A.s_next, S), A.label_real, [&] { p_g.issue(A.gen.wf + A.gg.offf[0]); });
   load_x0(tg.x0, row0, A.n_rows, gin(A.s, S), gin(A.a, Ad), nil(), nullptr);
   __syncthreads();
-  net_forward<NET_GEN, false>(A.gen.wf, A.gg, tg, none);
+  net_forward<NET_GEN, false>(A.gen.wf, A.gg, tg, none, p_g, [&] { p_d.issue(A.disc.wf + A.gd.offf[0]); });
   load_x0(td.x0, row0, A.n_rows, gin(A.s, S), lin(tg.out, LD_O, S), gin(A.a, Ad), nullptr);
   __syncthreads();
-  net_forward<NET_DISC, false>(A.disc.wf, A.gd, td, none);
+  net_forward<NET_DISC, false>(A.disc.wf, A.gd, td, none, p_d, NoNext{});
   float l = 0.f;
   if (threadIdx.x < ROWS && row0 + threadIdx.x < A.n_rows) l = sigmoid_ce(td.out[threadIdx.x * LD_O], 1.f);
   const float lg = sum16_lds(small, l);
@@ -339,11 +399,12 @@ __global__ __launch_bounds__(THREADS) void mlp_forward_kernel(const FwdArgs A) {
   const int row0 = blockIdx.x * ROWS;
   const int S = A.g.S, Ad = A.g.A;
   const ActsG none{};
+  Pre<NT_H, 2> p1; p1.issue(A.net.wf + A.g.offf[0]);
   if (KIND == NET_ACTOR) load_x0(t.x0, row0, A.n_rows, gin(A.s, S), nil(), nil(), nullptr);
   else if (KIND == NET_DISC) load_x0(t.x0, row0, A.n_rows, gin(A.s, S), gin(A.x, S), gin(A.a, Ad), nullptr);
   else load_x0(t.x0, row0, A.n_rows, gin(A.s, S), gin(A.a, Ad), nil(), nullptr);
   __syncthreads();
-  net_forward<KIND, false>(A.net.wf, A.g, t, none);
+  net_forward<KIND, false>(A.net.wf, A.g, t, none, p1, NoNext{});
   const int r = threadIdx.x >> 4, c = threadIdx.x & 15;
   if (row0 + r < A.n_rows && c < A.g.NOUT) {
     float v = t.out[r * LD_O + c];
@@ -354,51 +415,60 @@ __global__ __launch_bounds__(THREADS) void mlp_forward_kernel(const FwdArgs A) {
 }
 
 // ------------------------------------------------------------------------------------------
-// weight pass: G_l[chunk] = X_l[chunk rows]^T * dZ_l[chunk rows]
+// weight pass: G_l[chunk] = X_l[chunk rows]^T * dZ_l[chunk rows] for every layer of up to three networks
 // ------------------------------------------------------------------------------------------
-struct WItem { const float* X; const float* dZ; int ldx, ldz, nstrips, nt, goff, np; };
-struct WArgs {
-  WItem it[4];
-  int blk0[5];
-  int rows, chunk_rows, nchunks, gstride;
-  float* gslabs;
+constexpr int WD = 4;            // 16-row groups of operands kept in flight
+constexpr int MAX_WITEMS = 12;   // 3 networks x 4 layers
+struct WItem {
+  const float* X; const float* dZ; float* gout;     // gout: chunk 0 of this layer's padded gradient image
+  int ldx, ldz, nstrips, nt, np;
+  int n_groups, groups_per_chunk, gstride;          // 16-row groups in all / per chunk; floats between chunks
+  int blk0;                                         // first workgroup of this item
 };
+struct WArgs { WItem it[MAX_WITEMS]; int n_items; };
 
-// acc[i] += X[rows r0..r1, strip]^T * dZ[rows r0..r1, tile i], i < T: `xp` / `zp` are this lane's
-// operand addresses for row 0 (consecutive tiles 16 floats apart).  Operands of PIPE 4-row steps are
-// kept in flight; the loop body is branch-free (surplus steps multiply a zero by a re-read row).
+// acc[i] += X[groups g0..g1, strip]^T * dZ[groups g0..g1, tile i].  xq / zq: this lane's float4 address
+// in group 0 (work arrays are [group][column][16 rows]: lane (q, j) reads rows 4q..4q+3 of column j).
 template <int T>
-__device__ __forceinline__ void wgrad_pipe(f32x4 (&acc)[T], const float* __restrict__ xp, int ldx,
-                                           const float* __restrict__ zp, int ldz, int r0, int r1) {
-  const int n = (r1 - r0) >> 2;
+__device__ __forceinline__ void wgrad_pipe(f32x4 (&acc)[T], const float* __restrict__ xq, int xs,
+                                           const float* __restrict__ zq, int zs, int g0, int g1) {
+  const int n = g1 - g0;
   if (n <= 0) return;
-  const int nblk = (n + PIPE - 1) / PIPE;
-  const int last = r1 - 4;
-  float a[PIPE], b[PIPE][T];
+  const int nblk = (n + WD - 1) / WD;
+  const int last = g1 - 1;
+  const f32x4 zero{0.f, 0.f, 0.f, 0.f};
+  f32x4 a[WD], b[WD][T];
 #pragma unroll
-  for (int j = 0; j < PIPE; ++j) {
-    const int r = r0 + 4 * j, rc = min(r, last);
-    const float av = xp[(size_t)rc * ldx];
-    a[j] = r < r1 ? av : 0.f;
+  for (int j = 0; j < WD; ++j) {
+    const int g = g0 + j, gc = min(g, last);
+    const f32x4 av = *(const f32x4*)(xq + (size_t)gc * xs);
+    a[j] = g < g1 ? av : zero;
 #pragma unroll
-    for (int i = 0; i < T; ++i) b[j][i] = zp[(size_t)rc * ldz + 16 * i];
+    for (int i = 0; i < T; ++i) b[j][i] = *(const f32x4*)(zq + (size_t)gc * zs + i * 256);
   }
   for (int blk = 1; blk < nblk; ++blk) {
 #pragma unroll
-    for (int j = 0; j < PIPE; ++j) {
+    for (int j = 0; j < WD; ++j) {
 #pragma unroll
-      for (int i = 0; i < T; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j][i], acc[i], 0, 0, 0);
-      const int r = r0 + 4 * (blk * PIPE + j), rc = min(r, last);
-      const float av = xp[(size_t)rc * ldx];
-      a[j] = r < r1 ? av : 0.f;
+      for (int m = 0; m < 4; ++m) {
 #pragma unroll
-      for (int i = 0; i < T; ++i) b[j][i] = zp[(size_t)rc * ldz + 16 * i];
+        for (int i = 0; i < T; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][m], b[j][i][m], acc[i], 0, 0, 0);
+      }
+      const int g = g0 + blk * WD + j, gc = min(g, last);
+      const f32x4 av = *(const f32x4*)(xq + (size_t)gc * xs);
+      a[j] = g < g1 ? av : zero;
+#pragma unroll
+      for (int i = 0; i < T; ++i) b[j][i] = *(const f32x4*)(zq + (size_t)gc * zs + i * 256);
+      __builtin_amdgcn_sched_barrier(0);   // keep the refill WD groups ahead of its use
     }
   }
 #pragma unroll
-  for (int j = 0; j < PIPE; ++j) {
+  for (int j = 0; j < WD; ++j) {
 #pragma unroll
-    for (int i = 0; i < T; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j][i], acc[i], 0, 0, 0);
+    for (int m = 0; m < 4; ++m) {
+#pragma unroll
+      for (int i = 0; i < T; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][m], b[j][i][m], acc[i], 0, 0, 0);
+    }
   }
 }
 
@@ -406,22 +476,24 @@ __device__ __forceinline__ void wgrad_pipe(f32x4 (&acc)[T], const float* __restr
 // the four waves (each walks all rows of the chunk); the NT%4 left-over tiles are computed by all
 // four waves together, each taking a quarter of the rows, and summed through LDS in wave order.
 template <int NT>
-__device__ __forceinline__ void wpass_body(const WItem& it, int strip, int chunk, const WArgs& A, float* part) {
+__device__ __forceinline__ void wpass_body(const WItem& it, int strip, int chunk, float* part) {
   constexpr int TPW = NT / 4, REM = NT % 4, LDP = REM * 16 + 4;
   const int lane = threadIdx.x & 63, wave = wave_id();
-  const int rb = chunk * A.chunk_rows;
-  const int re = min(A.rows, rb + A.chunk_rows);
-  const float* xp = it.X + (size_t)(lane >> 4) * it.ldx + 16 * strip + (lane & 15);
-  const float* zp = it.dZ + (size_t)(lane >> 4) * it.ldz + (lane & 15);
-  float* gout = A.gslabs + (size_t)chunk * A.gstride + it.goff + (size_t)(16 * strip) * it.np;
+  const int q4 = (lane >> 4) * 4, j = lane & 15;
+  const int gb = chunk * it.groups_per_chunk;
+  const int ge = min(it.n_groups, gb + it.groups_per_chunk);
+  const int xs = it.ldx * 16, zs = it.ldz * 16;
+  const float* xq = it.X + (16 * strip + j) * 16 + q4;
+  const float* zq = it.dZ + j * 16 + q4;
+  float* gout = it.gout + (size_t)chunk * it.gstride + (size_t)(16 * strip) * it.np;
   if constexpr (REM > 0) {
-    const int rpw = A.chunk_rows >> 2;
-    const int w0 = rb + wave * rpw, w1 = min(re, w0 + rpw);
+    const int per = (it.groups_per_chunk + 3) >> 2;
+    const int w0 = gb + wave * per, w1 = min(ge, w0 + per);
     f32x4 accr[REM];
 #pragma unroll
     for (int i = 0; i < REM; ++i) accr[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    wgrad_pipe<REM>(accr, xp, it.ldx, zp + 16 * (4 * TPW), it.ldz, w0, w1);
-    float* pw = part + wave * ROWS * LDP + ((lane >> 4) * 4) * LDP + (lane & 15);
+    wgrad_pipe<REM>(accr, xq, xs, zq + (4 * TPW) * 256, zs, w0, w1);
+    float* pw = part + wave * ROWS * LDP + q4 * LDP + j;
 #pragma unroll
     for (int i = 0; i < REM; ++i) {
 #pragma unroll
@@ -432,12 +504,12 @@ __device__ __forceinline__ void wpass_body(const WItem& it, int strip, int chunk
     f32x4 acc[TPW];
 #pragma unroll
     for (int i = 0; i < TPW; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    wgrad_pipe<TPW>(acc, xp, it.ldx, zp + 16 * (wave * TPW), it.ldz, rb, re);
+    wgrad_pipe<TPW>(acc, xq, xs, zq + (wave * TPW) * 256, zs, gb, ge);
 #pragma unroll
     for (int i = 0; i < TPW; ++i) {
-      const int col = 16 * (wave * TPW + i) + (lane & 15);
+      const int col = 16 * (wave * TPW + i) + j;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) gout[((lane >> 4) * 4 + r) * (NT * 16) + col] = acc[i][r];
+      for (int r = 0; r < 4; ++r) gout[(q4 + r) * (NT * 16) + col] = acc[i][r];
     }
   }
   if constexpr (REM > 0) {
@@ -456,88 +528,122 @@ __global__ __launch_bounds__(THREADS) void wpass_kernel(const WArgs A) {
   __shared__ __attribute__((aligned(16))) float part[PART_FLOATS];
   int item = 0;
 #pragma unroll
-  for (int i = 1; i < 4; ++i) if ((int)blockIdx.x >= A.blk0[i]) item = i;
-  const int local = blockIdx.x - A.blk0[item];
-  // the item record is copied field by field so that it stays in scalar registers
-  WItem it;
-  it.X = A.it[0].X; it.dZ = A.it[0].dZ; it.ldx = A.it[0].ldx; it.ldz = A.it[0].ldz;
-  it.nstrips = A.it[0].nstrips; it.nt = A.it[0].nt; it.goff = A.it[0].goff; it.np = A.it[0].np;
+  for (int i = 1; i < MAX_WITEMS; ++i) if (i < A.n_items && (int)blockIdx.x >= A.it[i].blk0) item = i;
+  // the item record is copied field by field under a uniform select so that it stays in scalar registers
+  WItem it = A.it[0];
 #pragma unroll
-  for (int i = 1; i < 4; ++i) {
-    if (item == i) {
-      it.X = A.it[i].X; it.dZ = A.it[i].dZ; it.ldx = A.it[i].ldx; it.ldz = A.it[i].ldz;
-      it.nstrips = A.it[i].nstrips; it.nt = A.it[i].nt; it.goff = A.it[i].goff; it.np = A.it[i].np;
-    }
-  }
+  for (int i = 1; i < MAX_WITEMS; ++i) if (item == i) it = A.it[i];
+  const int local = blockIdx.x - it.blk0;
   const int strip = local % it.nstrips, chunk = local / it.nstrips;
-  if (it.nt == NT_H) wpass_body<NT_H>(it, strip, chunk, A, part);
-  else if (it.nt == 4) wpass_body<4>(it, strip, chunk, A, part);
-  else wpass_body<1>(it, strip, chunk, A, part);
+  if (it.nt == NT_H) wpass_body<NT_H>(it, strip, chunk, part);
+  else if (it.nt == 4) wpass_body<4>(it, strip, chunk, part);
+  else wpass_body<1>(it, strip, chunk, part);
 }
 
 // ------------------------------------------------------------------------------------------
-// reduction over chunks, optimizers, target update, packing
+// reduction over chunks, optimizers, target update, packing -- each for up to three networks a launch
 // ------------------------------------------------------------------------------------------
 constexpr int MAX_CHUNKS = 16;
-__global__ void grad_reduce_kernel(const float* __restrict__ gslabs, int nchunks, int gstride,
-                                   const int32_t* __restrict__ map_g, int n, float* __restrict__ grad,
-                                   const float* loss_parts, int n_parts, float loss_scale, float* loss_out,
-                                   int32_t* counter) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p < n) {
-    const float* src = gslabs + map_g[p];
+constexpr int MAX_JOBS = 4;
+
+struct ReduceJob {
+  const float* gslabs; const int32_t* map_g; float* grad;
+  const float* loss_parts; float* loss_out; int32_t* counter;
+  int nchunks, gstride, n, n_parts; float loss_scale; int blk0;
+};
+struct ReduceArgs { ReduceJob job[MAX_JOBS]; int n_jobs; };
+
+__global__ __launch_bounds__(256) void grad_reduce_kernel(const ReduceArgs A) {
+  int ji = 0;
+#pragma unroll
+  for (int i = 1; i < MAX_JOBS; ++i) if (i < A.n_jobs && (int)blockIdx.x >= A.job[i].blk0) ji = i;
+  ReduceJob J = A.job[0];
+#pragma unroll
+  for (int i = 1; i < MAX_JOBS; ++i) if (ji == i) J = A.job[i];
+  const int blk = blockIdx.x - J.blk0;
+  const int p = blk * 256 + threadIdx.x;
+  if (p < J.n) {
+    const float* src = J.gslabs + J.map_g[p];
     float v[MAX_CHUNKS];
 #pragma unroll
-    for (int c = 0; c < MAX_CHUNKS; ++c) v[c] = c < nchunks ? src[(size_t)c * gstride] : 0.f;
+    for (int c = 0; c < MAX_CHUNKS; ++c) v[c] = c < J.nchunks ? src[(size_t)c * J.gstride] : 0.f;
     float s = 0.f;
 #pragma unroll
     for (int c = 0; c < MAX_CHUNKS; ++c) s += v[c];          // chunk order: bitwise reproducible
-    grad[p] = s;
+    J.grad[p] = s;
   }
-  if (blockIdx.x == 0 && threadIdx.x < 64) {
-    if (loss_out) {
+  if (blk == 0 && threadIdx.x < 64) {
+    if (J.loss_out) {
       // 64 lanes, each sums a strided share in index order, then a fixed-order lane reduction
       float s = 0.f;
-      for (int i = threadIdx.x; i < n_parts; i += 64) s += loss_parts[i];
+      for (int i = threadIdx.x; i < J.n_parts; i += 64) s += J.loss_parts[i];
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
-      if (threadIdx.x == 0) loss_out[0] = s * loss_scale;
+      if (threadIdx.x == 0) J.loss_out[0] = s * J.loss_scale;
     }
-    if (counter && threadIdx.x == 0) counter[0] += 1;
+    if (J.counter && threadIdx.x == 0) J.counter[0] += 1;
   }
 }
 
-__global__ void rmsprop_kernel(float* __restrict__ canon, const float* __restrict__ grad, float* __restrict__ ms,
-                               int n, float lr, float decay, float eps, const int32_t* __restrict__ map_f,
-                               float* __restrict__ wf, const int32_t* __restrict__ map_b, float* __restrict__ wb) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= n) return;
-  const float g = grad[p];
-  const float m = decay * ms[p] + (1.f - decay) * g * g;
-  ms[p] = m;
-  const float w = canon[p] - lr * g / sqrtf(m + eps);
-  canon[p] = w;
-  wf[map_f[p]] = w;
-  if (wb) { const int ob = map_b[p]; if (ob >= 0) wb[ob] = w; }
+// one optimizer step of one network, optionally followed by its target-network update
+struct ApplyJob {
+  float* canon; const float* grad; float* slot0; float* slot1;
+  const int32_t* map_f; float* wf; const int32_t* map_b; float* wb;
+  const int32_t* step;                 // Adam: bias-correction step count (already incremented)
+  float* target_canon; float* target_wf; const int32_t* counter;   // target update (NULL: none)
+  double lr, beta1, beta2;             // RMSProp: beta1 = decay
+  float eps, tau;
+  int opt, n, period, blk0;            // opt: 0 = RMSProp, 1 = Adam
+};
+struct ApplyArgs { ApplyJob job[MAX_JOBS]; int n_jobs; };
+
+__global__ __launch_bounds__(256) void apply_kernel(const ApplyArgs A) {
+  int ji = 0;
+#pragma unroll
+  for (int i = 1; i < MAX_JOBS; ++i) if (i < A.n_jobs && (int)blockIdx.x >= A.job[i].blk0) ji = i;
+  ApplyJob J = A.job[0];
+#pragma unroll
+  for (int i = 1; i < MAX_JOBS; ++i) if (ji == i) J = A.job[i];
+  const int p = (blockIdx.x - J.blk0) * 256 + threadIdx.x;
+  if (p >= J.n) return;
+  const float g = J.grad[p];
+  float w;
+  if (J.opt == 0) {
+    // tf.train.RMSPropOptimizer: ms <- decay*ms + (1-decay)*g^2 ; w <- w - lr*g/sqrt(ms + eps)
+    const float decay = (float)J.beta1;
+    const float m = decay * J.slot0[p] + (1.f - decay) * g * g;
+    J.slot0[p] = m;
+    w = J.canon[p] - (float)J.lr * g / sqrtf(m + J.eps);
+  } else {
+    // tf.train.AdamOptimizer: lr_t = lr*sqrt(1-b2^t)/(1-b1^t); w <- w - lr_t*m/(sqrt(v)+eps)
+    const int t = J.step[0];
+    const float lr_t = (float)(J.lr * sqrt(1.0 - pow(J.beta2, (double)t)) / (1.0 - pow(J.beta1, (double)t)));
+    const float fb1 = (float)J.beta1, fb2 = (float)J.beta2;
+    const float m = fb1 * J.slot0[p] + (1.f - fb1) * g;
+    const float v = fb2 * J.slot1[p] + (1.f - fb2) * g * g;
+    J.slot0[p] = m; J.slot1[p] = v;
+    w = J.canon[p] - lr_t * m / (sqrtf(v) + J.eps);
+  }
+  J.canon[p] = w;
+  const int of = J.map_f[p];
+  J.wf[of] = w;
+  if (J.wb) { const int ob = J.map_b[p]; if (ob >= 0) J.wb[ob] = w; }
+  if (J.target_canon && (!J.counter || ((J.counter[0] - 1) % J.period) == 0)) {
+    // hard copy (tau = 1, DDPG.py:99-101,176-178) or Polyak average
+    const float tw = J.tau == 1.f ? w : J.tau * w + (1.f - J.tau) * J.target_canon[p];
+    J.target_canon[p] = tw;
+    J.target_wf[of] = tw;
+  }
 }
 
-__global__ void adam_kernel(float* __restrict__ canon, const float* __restrict__ grad, float* __restrict__ m1,
-                            float* __restrict__ m2, int n, double lr, double b1, double b2, float eps,
-                            const int32_t* __restrict__ step, const int32_t* __restrict__ map_f,
-                            float* __restrict__ wf, const int32_t* __restrict__ map_b, float* __restrict__ wb) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= n) return;
-  const int t = step[0];
-  const float lr_t = (float)(lr * sqrt(1.0 - pow(b2, (double)t)) / (1.0 - pow(b1, (double)t)));
-  const float fb1 = (float)b1, fb2 = (float)b2;
-  const float g = grad[p];
-  const float m = fb1 * m1[p] + (1.f - fb1) * g;
-  const float v = fb2 * m2[p] + (1.f - fb2) * g * g;
-  m1[p] = m; m2[p] = v;
-  const float w = canon[p] - lr_t * m / (sqrtf(v) + eps);
-  canon[p] = w;
-  wf[map_f[p]] = w;
-  if (wb) { const int ob = map_b[p]; if (ob >= 0) wb[ob] = w; }
+// out[k] = scale * sum_i parts[k*n_parts + i], one wave per sum, fixed order
+__global__ void sum_parts_kernel(const float* __restrict__ parts, int n_parts, float scale, float* __restrict__ out) {
+  const float* p = parts + (size_t)blockIdx.x * n_parts;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n_parts; i += 64) s += p[i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+  if (threadIdx.x == 0) out[blockIdx.x] = s * scale;
 }
 
 __global__ void target_update_kernel(float* __restrict__ tc, const float* __restrict__ ec, int n, float tau,
@@ -573,6 +679,48 @@ inline bool acts_ok(const rlgan_acts_t& a) {
 }
 inline int launched() { return (int)hipGetLastError(); }
 
+// ---- argument validation / packing shared by the single-step and the fused-phase entry points
+int make_critic_args(CriticArgs& A, const rlgan_critic_step_t* c) {
+  if (!c) return RLGAN_E_ARG;
+  if (!make_geo(NET_CRITIC, c->s_dim, c->a_dim, A.gc) || !make_geo(NET_ACTOR, c->s_dim, c->a_dim, A.ga)) return RLGAN_E_DIMS;
+  if (c->n_rows <= 0 || !c->critic_eval.wf || !c->critic_eval.wb || !c->critic_target.wf || !c->actor_target.wf ||
+      !c->s.p || !c->a.p || !c->r.p || !c->s_next.p || !c->loss_parts || !acts_ok(c->acts_critic)) return RLGAN_E_ARG;
+  A.train_actor = c->actor_eval.wf != nullptr;
+  if (A.train_actor && (!c->actor_eval.wb || !acts_ok(c->acts_actor))) return RLGAN_E_ARG;
+  A.critic_e = NP(c->critic_eval); A.critic_t = NP(c->critic_target); A.actor_t = NP(c->actor_target); A.actor_e = NP(c->actor_eval);
+  A.s = M(c->s); A.a = M(c->a); A.r = M(c->r); A.s_next = M(c->s_next);
+  A.gamma = c->gamma; A.inv_gb = c->inv_global_batch; A.n_rows = c->n_rows;
+  A.acts_c = A8(c->acts_critic); A.acts_a = A8(c->acts_actor); A.loss_parts = c->loss_parts;
+  return 0;
+}
+int make_actor_args(ActorArgs& A, const rlgan_actor_step_t* c) {
+  if (!c) return RLGAN_E_ARG;
+  if (!make_geo(NET_CRITIC, c->s_dim, c->a_dim, A.gc) || !make_geo(NET_ACTOR, c->s_dim, c->a_dim, A.ga)) return RLGAN_E_DIMS;
+  if (c->n_rows <= 0 || !c->actor_eval.wf || !c->actor_eval.wb || !c->critic_eval.wf || !c->critic_eval.wb || !c->s.p ||
+      !acts_ok(c->acts_actor)) return RLGAN_E_ARG;
+  A.actor_e = NP(c->actor_eval); A.critic_e = NP(c->critic_eval); A.s = M(c->s); A.n_rows = c->n_rows; A.acts_a = A8(c->acts_actor);
+  return 0;
+}
+int make_disc_args(DiscArgs& A, const rlgan_disc_step_t* c) {
+  if (!c) return RLGAN_E_ARG;
+  if (!make_geo(NET_DISC, c->s_dim, c->a_dim, A.gd)) return RLGAN_E_DIMS;
+  if (c->n_rows <= 0 || !c->disc.wf || !c->disc.wb || !c->s.p || !c->g_stored.p || !c->a.p || !c->s_next.p || !c->loss_parts ||
+      !acts_ok(c->acts_disc)) return RLGAN_E_ARG;
+  A.disc = NP(c->disc); A.s = M(c->s); A.g = M(c->g_stored); A.a = M(c->a); A.s_next = M(c->s_next);
+  A.label_real = c->label_real; A.inv_gb = c->inv_global_batch; A.n_rows = c->n_rows; A.rows16 = cdiv(c->n_rows, ROWS) * ROWS;
+  A.acts_d = A8(c->acts_disc); A.loss_parts = c->loss_parts;
+  return 0;
+}
+int make_gen_args(GenArgs& A, const rlgan_gen_step_t* c) {
+  if (!c) return RLGAN_E_ARG;
+  if (!make_geo(NET_GEN, c->s_dim, c->a_dim, A.gg) || !make_geo(NET_DISC, c->s_dim, c->a_dim, A.gd)) return RLGAN_E_DIMS;
+  if (c->n_rows <= 0 || !c->gen.wf || !c->gen.wb || !c->disc.wf || !c->disc.wb || !c->s.p || !c->a.p || !c->loss_parts ||
+      !acts_ok(c->acts_gen)) return RLGAN_E_ARG;
+  A.gen = NP(c->gen); A.disc = NP(c->disc); A.s = M(c->s); A.a = M(c->a); A.inv_gb = c->inv_global_batch; A.n_rows = c->n_rows;
+  A.acts_g = A8(c->acts_gen); A.loss_parts = c->loss_parts;
+  return 0;
+}
+
 }  // namespace
 
 // ==============================================================================================
@@ -580,62 +728,49 @@ inline int launched() { return (int)hipGetLastError(); }
 // ==============================================================================================
 extern "C" {
 
-int rlgan_critic_step_rows(int s_dim, int a_dim, rlgan_net_t critic_eval, rlgan_net_t critic_target,
-                           rlgan_net_t actor_target, rlgan_net_t actor_eval,
-                           rlgan_mat_t s, rlgan_mat_t a, rlgan_mat_t r, rlgan_mat_t s_next,
-                           float gamma, float inv_global_batch, int n_rows,
-                           rlgan_acts_t acts_critic, rlgan_acts_t acts_actor,
-                           float* loss_parts, void* stream) {
+int rlgan_critic_step_rows(const rlgan_critic_step_t* c, void* stream) {
   CriticArgs A;
-  if (!make_geo(NET_CRITIC, s_dim, a_dim, A.gc) || !make_geo(NET_ACTOR, s_dim, a_dim, A.ga)) return RLGAN_E_DIMS;
-  if (n_rows <= 0 || !critic_eval.wf || !critic_eval.wb || !critic_target.wf || !actor_target.wf ||
-      !s.p || !a.p || !r.p || !s_next.p || !loss_parts || !acts_ok(acts_critic)) return RLGAN_E_ARG;
-  A.train_actor = actor_eval.wf != nullptr;
-  if (A.train_actor && (!actor_eval.wb || !acts_ok(acts_actor))) return RLGAN_E_ARG;
-  A.critic_e = NP(critic_eval); A.critic_t = NP(critic_target); A.actor_t = NP(actor_target); A.actor_e = NP(actor_eval);
-  A.s = M(s); A.a = M(a); A.r = M(r); A.s_next = M(s_next);
-  A.gamma = gamma; A.inv_gb = inv_global_batch; A.n_rows = n_rows;
-  A.acts_c = A8(acts_critic); A.acts_a = A8(acts_actor); A.loss_parts = loss_parts;
-  hipLaunchKernelGGL(critic_step_kernel, dim3(cdiv(n_rows, ROWS)), dim3(THREADS), 0, (hipStream_t)stream, A);
+  if (const int rc = make_critic_args(A, c)) return rc;
+  hipLaunchKernelGGL(critic_step_kernel, dim3(cdiv(A.n_rows, ROWS)), dim3(THREADS), 0, (hipStream_t)stream, A);
   return launched();
 }
 
-int rlgan_actor_step_rows(int s_dim, int a_dim, rlgan_net_t actor_eval, rlgan_net_t critic_eval,
-                          rlgan_mat_t s, int n_rows, rlgan_acts_t acts_actor, void* stream) {
+int rlgan_actor_step_rows(const rlgan_actor_step_t* c, void* stream) {
   ActorArgs A;
-  if (!make_geo(NET_CRITIC, s_dim, a_dim, A.gc) || !make_geo(NET_ACTOR, s_dim, a_dim, A.ga)) return RLGAN_E_DIMS;
-  if (n_rows <= 0 || !actor_eval.wf || !actor_eval.wb || !critic_eval.wf || !critic_eval.wb || !s.p ||
-      !acts_ok(acts_actor)) return RLGAN_E_ARG;
-  A.actor_e = NP(actor_eval); A.critic_e = NP(critic_eval); A.s = M(s); A.n_rows = n_rows; A.acts_a = A8(acts_actor);
-  hipLaunchKernelGGL(actor_step_kernel, dim3(cdiv(n_rows, ROWS)), dim3(THREADS), 0, (hipStream_t)stream, A);
+  if (const int rc = make_actor_args(A, c)) return rc;
+  hipLaunchKernelGGL(actor_step_kernel, dim3(cdiv(A.n_rows, ROWS)), dim3(THREADS), 0, (hipStream_t)stream, A);
   return launched();
 }
 
-int rlgan_disc_step_rows(int s_dim, int a_dim, rlgan_net_t disc,
-                         rlgan_mat_t s, rlgan_mat_t g_stored, rlgan_mat_t a, rlgan_mat_t s_next,
-                         float label_real, float inv_global_batch, int n_rows,
-                         rlgan_acts_t acts_disc, float* loss_parts, void* stream) {
+int rlgan_disc_step_rows(const rlgan_disc_step_t* c, void* stream) {
   DiscArgs A;
-  if (!make_geo(NET_DISC, s_dim, a_dim, A.gd)) return RLGAN_E_DIMS;
-  if (n_rows <= 0 || !disc.wf || !disc.wb || !s.p || !g_stored.p || !a.p || !s_next.p || !loss_parts ||
-      !acts_ok(acts_disc)) return RLGAN_E_ARG;
-  A.disc = NP(disc); A.s = M(s); A.g = M(g_stored); A.a = M(a); A.s_next = M(s_next);
-  A.label_real = label_real; A.inv_gb = inv_global_batch; A.n_rows = n_rows; A.rows16 = cdiv(n_rows, ROWS) * ROWS;
-  A.acts_d = A8(acts_disc); A.loss_parts = loss_parts;
-  hipLaunchKernelGGL(disc_step_kernel, dim3(cdiv(n_rows, ROWS)), dim3(THREADS), 0, (hipStream_t)stream, A);
+  if (const int rc = make_disc_args(A, c)) return rc;
+  hipLaunchKernelGGL(disc_step_kernel, dim3(cdiv(A.n_rows, ROWS)), dim3(THREADS), 0, (hipStream_t)stream, A);
   return launched();
 }
 
-int rlgan_gen_step_rows(int s_dim, int a_dim, rlgan_net_t gen, rlgan_net_t disc,
-                        rlgan_mat_t s, rlgan_mat_t a, float inv_global_batch, int n_rows,
-                        rlgan_acts_t acts_gen, float* loss_parts, void* stream) {
+int rlgan_gen_step_rows(const rlgan_gen_step_t* c, void* stream) {
   GenArgs A;
-  if (!make_geo(NET_GEN, s_dim, a_dim, A.gg) || !make_geo(NET_DISC, s_dim, a_dim, A.gd)) return RLGAN_E_DIMS;
-  if (n_rows <= 0 || !gen.wf || !gen.wb || !disc.wf || !disc.wb || !s.p || !a.p || !loss_parts ||
-      !acts_ok(acts_gen)) return RLGAN_E_ARG;
-  A.gen = NP(gen); A.disc = NP(disc); A.s = M(s); A.a = M(a); A.inv_gb = inv_global_batch; A.n_rows = n_rows;
-  A.acts_g = A8(acts_gen); A.loss_parts = loss_parts;
-  hipLaunchKernelGGL(gen_step_kernel, dim3(cdiv(n_rows, ROWS)), dim3(THREADS), 0, (hipStream_t)stream, A);
+  if (const int rc = make_gen_args(A, c)) return rc;
+  hipLaunchKernelGGL(gen_step_kernel, dim3(cdiv(A.n_rows, ROWS)), dim3(THREADS), 0, (hipStream_t)stream, A);
+  return launched();
+}
+
+int rlgan_phase1_rows(const rlgan_critic_step_t* c, const rlgan_disc_step_t* d, void* stream) {
+  CriticArgs C; DiscArgs D;
+  if (const int rc = make_critic_args(C, c)) return rc;
+  if (const int rc = make_disc_args(D, d)) return rc;
+  if (C.n_rows != D.n_rows) return RLGAN_E_ALIGN;
+  hipLaunchKernelGGL(phase1_kernel, dim3(2 * cdiv(C.n_rows, ROWS)), dim3(THREADS), 0, (hipStream_t)stream, C, D);
+  return launched();
+}
+
+int rlgan_phase2_rows(const rlgan_actor_step_t* a, const rlgan_gen_step_t* g, void* stream) {
+  ActorArgs Aa; GenArgs G;
+  if (const int rc = make_actor_args(Aa, a)) return rc;
+  if (const int rc = make_gen_args(G, g)) return rc;
+  if (Aa.n_rows != G.n_rows) return RLGAN_E_ALIGN;
+  hipLaunchKernelGGL(phase2_kernel, dim3(2 * cdiv(Aa.n_rows, ROWS)), dim3(THREADS), 0, (hipStream_t)stream, Aa, G);
   return launched();
 }
 
@@ -680,55 +815,79 @@ int rlgan_wgrad_chunks(int rows, int32_t* chunk_rows, int32_t* n_chunks) {
   return 0;
 }
 
-int rlgan_weight_grads(int kind, int s_dim, int a_dim, rlgan_acts_t acts, int rows, float* gslabs, void* stream) {
-  Geo g;
-  if (kind < 0 || kind > 3) return RLGAN_E_KIND;
-  if (!make_geo(kind, s_dim, a_dim, g)) return RLGAN_E_DIMS;
-  if (!acts_ok(acts) || !gslabs) return RLGAN_E_ARG;
+int rlgan_weight_grads(const rlgan_wgrad_job_t* jobs, int n_jobs, int s_dim, int a_dim, void* stream) {
+  if (!jobs || n_jobs <= 0 || 4 * n_jobs > MAX_WITEMS) return RLGAN_E_ARG;
   WArgs A;
-  int32_t cr, nc;
-  const int rc = rlgan_wgrad_chunks(rows, &cr, &nc);
-  if (rc) return rc;
-  A.rows = rows; A.chunk_rows = cr; A.nchunks = nc; A.gstride = g.gpad_floats; A.gslabs = gslabs;
-  const float* X[4] = {acts.x0, acts.h1, acts.h2, acts.h3};
-  const float* Z[4] = {acts.dz1, acts.dz2, acts.dz3, acts.dz4};
-  const int ldx[4] = {X0_COLS, NP_H, NP_H, g.ld3};
-  const int ldz[4] = {NP_H, NP_H, g.ld3, 16};
+  A.n_items = 0;
   int b = 0;
-  for (int l = 0; l < 4; ++l) {
-    A.it[l] = WItem{X[l], Z[l], ldx[l], ldz[l], g.kp[l] / 16, g.ntf[l], g.goff[l], g.np[l]};
-    A.blk0[l] = b;
-    b += (g.kp[l] / 16) * nc;
+  for (int ji = 0; ji < n_jobs; ++ji) {
+    const rlgan_wgrad_job_t& J = jobs[ji];
+    Geo g;
+    if (J.kind < 0 || J.kind > 3) return RLGAN_E_KIND;
+    if (!make_geo(J.kind, s_dim, a_dim, g)) return RLGAN_E_DIMS;
+    if (!acts_ok(J.acts) || !J.gslabs) return RLGAN_E_ARG;
+    int32_t cr, nc;
+    if (const int rc = rlgan_wgrad_chunks(J.rows, &cr, &nc)) return rc;
+    const float* X[4] = {J.acts.x0, J.acts.h1, J.acts.h2, J.acts.h3};
+    const float* Z[4] = {J.acts.dz1, J.acts.dz2, J.acts.dz3, J.acts.dz4};
+    const int ldx[4] = {X0_COLS, NP_H, NP_H, g.ld3};
+    const int ldz[4] = {NP_H, NP_H, g.ld3, 16};
+    for (int l = 0; l < 4; ++l) {
+      WItem& it = A.it[A.n_items++];
+      it.X = X[l]; it.dZ = Z[l]; it.gout = J.gslabs + g.goff[l];
+      it.ldx = ldx[l]; it.ldz = ldz[l]; it.nstrips = g.kp[l] / 16; it.nt = g.ntf[l]; it.np = g.np[l];
+      it.n_groups = J.rows / ROWS; it.groups_per_chunk = cr / ROWS; it.gstride = g.gpad_floats;
+      it.blk0 = b;
+      b += it.nstrips * nc;
+    }
   }
-  A.blk0[4] = b;
   hipLaunchKernelGGL(wpass_kernel, dim3(b), dim3(THREADS), 0, (hipStream_t)stream, A);
   return launched();
 }
 
-int rlgan_grad_reduce(const float* gslabs, int n_chunks, int gpad_floats, const int32_t* map_g,
-                      int n_params, float* grad, const float* loss_parts, int n_parts,
-                      float loss_scale, float* loss_out, int32_t* counter, void* stream) {
-  if (!gslabs || !map_g || !grad || n_params <= 0 || n_chunks <= 0 || n_chunks > MAX_CHUNKS || (loss_out && !loss_parts)) return RLGAN_E_ARG;
-  hipLaunchKernelGGL(grad_reduce_kernel, dim3(cdiv(n_params, 256)), dim3(256), 0, (hipStream_t)stream,
-                     gslabs, n_chunks, gpad_floats, map_g, n_params, grad, loss_parts, n_parts, loss_scale,
-                     loss_out, counter);
+int rlgan_grad_reduce(const rlgan_reduce_job_t* jobs, int n_jobs, void* stream) {
+  if (!jobs || n_jobs <= 0 || n_jobs > MAX_JOBS) return RLGAN_E_ARG;
+  ReduceArgs A;
+  A.n_jobs = n_jobs;
+  int b = 0;
+  for (int i = 0; i < n_jobs; ++i) {
+    const rlgan_reduce_job_t& J = jobs[i];
+    if (!J.gslabs || !J.map_g || !J.grad || J.n_params <= 0 || J.n_chunks <= 0 || J.n_chunks > MAX_CHUNKS ||
+        (J.loss_out && !J.loss_parts)) return RLGAN_E_ARG;
+    A.job[i] = ReduceJob{J.gslabs, J.map_g, J.grad, J.loss_parts, J.loss_out, J.counter,
+                         J.n_chunks, J.gpad_floats, J.n_params, J.n_parts, J.loss_scale, b};
+    b += cdiv(J.n_params, 256);
+  }
+  hipLaunchKernelGGL(grad_reduce_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, A);
   return launched();
 }
 
-int rlgan_rmsprop_apply(float* canon, const float* grad, float* ms, int n_params, float lr, float decay, float eps,
-                        const int32_t* map_f, float* wf, const int32_t* map_b, float* wb, void* stream) {
-  if (!canon || !grad || !ms || !map_f || !wf || n_params <= 0 || (wb && !map_b)) return RLGAN_E_ARG;
-  hipLaunchKernelGGL(rmsprop_kernel, dim3(cdiv(n_params, 256)), dim3(256), 0, (hipStream_t)stream,
-                     canon, grad, ms, n_params, lr, decay, eps, map_f, wf, map_b, wb);
+int rlgan_apply(const rlgan_apply_job_t* jobs, int n_jobs, void* stream) {
+  if (!jobs || n_jobs <= 0 || n_jobs > MAX_JOBS) return RLGAN_E_ARG;
+  ApplyArgs A;
+  A.n_jobs = n_jobs;
+  int b = 0;
+  for (int i = 0; i < n_jobs; ++i) {
+    const rlgan_apply_job_t& J = jobs[i];
+    if (!J.canon || !J.grad || !J.slot0 || !J.map_f || !J.wf || J.n_params <= 0 || (J.wb && !J.map_b)) return RLGAN_E_ARG;
+    if (J.opt != 0 && J.opt != 1) return RLGAN_E_ARG;
+    if (J.opt == 1 && (!J.slot1 || !J.step)) return RLGAN_E_ARG;
+    if (J.target_canon && (!J.target_wf || (J.counter && J.period <= 0))) return RLGAN_E_ARG;
+    ApplyJob& K = A.job[i];
+    K.canon = J.canon; K.grad = J.grad; K.slot0 = J.slot0; K.slot1 = J.slot1;
+    K.map_f = J.map_f; K.wf = J.wf; K.map_b = J.map_b; K.wb = J.wb; K.step = J.step;
+    K.target_canon = J.target_canon; K.target_wf = J.target_wf; K.counter = J.counter;
+    K.lr = J.lr; K.beta1 = J.beta1; K.beta2 = J.beta2; K.eps = J.eps; K.tau = J.tau;
+    K.opt = J.opt; K.n = J.n_params; K.period = J.period; K.blk0 = b;
+    b += cdiv(J.n_params, 256);
+  }
+  hipLaunchKernelGGL(apply_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, A);
   return launched();
 }
 
-int rlgan_adam_apply(float* canon, const float* grad, float* m, float* v, int n_params,
-                     double lr, double beta1, double beta2, float eps, const int32_t* step,
-                     const int32_t* map_f, float* wf, const int32_t* map_b, float* wb, void* stream) {
-  if (!canon || !grad || !m || !v || !step || !map_f || !wf || n_params <= 0 || (wb && !map_b)) return RLGAN_E_ARG;
-  hipLaunchKernelGGL(adam_kernel, dim3(cdiv(n_params, 256)), dim3(256), 0, (hipStream_t)stream,
-                     canon, grad, m, v, n_params, lr, beta1, beta2, eps, step, map_f, wf, map_b, wb);
+int rlgan_sum_parts(const float* parts, int n_parts, int n_sums, float scale, float* out, void* stream) {
+  if (!parts || !out || n_parts <= 0 || n_sums <= 0) return RLGAN_E_ARG;
+  hipLaunchKernelGGL(sum_parts_kernel, dim3(n_sums), dim3(64), 0, (hipStream_t)stream, parts, n_parts, scale, out);
   return launched();
 }
 

@@ -5,9 +5,12 @@
 //   Z[16, N] = X[16, K+1] * [W ; b]                 (bias folded in as the row of a constant-1 column)
 // done with v_mfma_f32_16x16x4_f32 (exact f32 FMA chains).  The 16-wide column tiles of a layer are
 // dealt to the four waves; X lives in LDS (it is shared by the waves); the weights are streamed
-// straight from L2 into registers as ready-made B fragments, several k-steps ahead of their use
-// (each wave reads a private share of them exactly once, so staging them in LDS would only add a
-// round trip).  Layers with a single column tile split K over the waves instead.
+// straight from L2 into registers as ready-made B fragments (each wave reads a private share of them
+// exactly once, so staging them in LDS would only add a round trip).  K is walked in groups of 16:
+// one 16-byte load per lane brings the B operands of four consecutive MFMAs of a tile, one
+// ds_read_b128 their A operands; GD groups are kept in flight and the first GD groups of the NEXT
+// layer are requested before the current layer's epilogue, so the L2/Infinity-Cache latency of the
+// weight stream hides behind arithmetic.  Tiles left over after the deal split K over the waves.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -22,10 +25,12 @@ enum { NET_ACTOR = 0, NET_CRITIC = 1, NET_GEN = 2, NET_DISC = 3 };
 constexpr int HID = 200;        // DDPG.py:82,159 ; Curious_GAN.py:59,121
 constexpr int NT_H = 13;        // 16-wide column tiles of a hidden layer
 constexpr int NP_H = 208;       // padded hidden width (global work arrays)
-constexpr int LD_W = 209;       // LDS stride of a wide activation tile (odd: conflict-free column reads)
-constexpr int LD_X0 = 33;       // LDS stride of the network-input tile (32 columns)
-constexpr int LD_O = 17;        // LDS stride of a 16-column tile
-constexpr int LD_3W = 65;       // LDS stride of a 64-column tile
+// LDS row strides: multiples of 4 floats (the A operand is read 16 bytes per lane) chosen so that the
+// 16 rows a ds_read_b128 lane group touches fall on 16 disjoint 4-bank slots of the 64 banks
+constexpr int LD_W = 212;       // wide activation tile (208 columns)
+constexpr int LD_X0 = 36;       // network-input tile (32 columns)
+constexpr int LD_O = 20;        // 16-column tile
+constexpr int LD_3W = 68;       // 64-column tile
 constexpr int X0_COLS = 32;     // global leading dimension of x0 work arrays
 constexpr int ROWS = 16;        // minibatch rows per workgroup
 constexpr int THREADS = 256;
@@ -35,8 +40,8 @@ constexpr float LRELU_ALPHA = 0.2f;  // Curious_GAN.py:56
 struct Geo {
   int S, A, K0, N3, NOUT, NT3;
   int K[4], N[4];
-  int nsf[4], ntf[4], offf[4];   // forward fragments: k-steps, column tiles, float offset in wf
-  int nsb[4], ntb[4], offb[4];   // backward fragments (W^T)
+  int ngf[4], ntf[4], offf[4];   // forward fragments: k-groups (16 k each), column tiles, float offset in wf
+  int ngb[4], ntb[4], offb[4];   // backward fragments (W^T)
   int kp[4], np[4], goff[4];     // padded gradient image [kp][np] per layer
   int n_params, wf_floats, wb_floats, gpad_floats, ld3;
 };
@@ -58,8 +63,8 @@ __host__ __device__ inline bool make_geo(int kind, int S, int A, Geo& g) {
   g.K[0] = g.K0; g.N[0] = HID; g.K[1] = HID; g.N[1] = HID; g.K[2] = HID; g.N[2] = g.N3; g.K[3] = g.N3; g.N[3] = g.NOUT;
   int of = 0, ob = 0, og = 0, np_ = 0;
   for (int l = 0; l < 4; ++l) {
-    g.nsf[l] = cdiv(g.K[l] + 1, 4); g.ntf[l] = cdiv(g.N[l], 16); g.offf[l] = of; of += g.nsf[l] * g.ntf[l] * 64;
-    g.nsb[l] = cdiv(g.N[l], 4);     g.ntb[l] = cdiv(g.K[l], 16); g.offb[l] = ob; ob += g.nsb[l] * g.ntb[l] * 64;
+    g.ngf[l] = l == 0 ? 2 : cdiv(g.K[l] + 1, 16); g.ntf[l] = cdiv(g.N[l], 16); g.offf[l] = of; of += g.ngf[l] * g.ntf[l] * 256;
+    g.ngb[l] = cdiv(g.N[l], 16);                  g.ntb[l] = cdiv(g.K[l], 16); g.offb[l] = ob; ob += g.ngb[l] * g.ntb[l] * 256;
     g.kp[l] = 16 * cdiv(g.K[l] + 1, 16); g.np[l] = 16 * g.ntf[l]; g.goff[l] = og; og += g.kp[l] * g.np[l];
     np_ += (g.K[l] + 1) * g.N[l];
   }
@@ -67,16 +72,17 @@ __host__ __device__ inline bool make_geo(int kind, int S, int A, Geo& g) {
   return true;
 }
 
+// Fragment image of an operand matrix B[k][n] (k-groups of 16, column tiles of 16): the four MFMAs
+// m = 0..3 of a group take k = 16*group + 4*(lane/16) + m, so lane `lane` of tile `t` holds its four
+// B values of a group in one float4 at ((group*NT + t)*64 + lane)*4.
+__host__ __device__ inline int frag_offset(int nt, int k, int n) {
+  const int kg = k >> 4, q = (k & 15) >> 2, m = k & 3, t = n >> 4, lane = (q << 4) | (n & 15);
+  return ((kg * nt + t) * 64 + lane) * 4 + m;
+}
 // float offset of element (k, n) of layer l in the forward-fragment image (k == K[l] is the bias row)
-__host__ __device__ inline int wf_offset(const Geo& g, int l, int k, int n) {
-  const int s = k >> 2, t = n >> 4, lane = ((k & 3) << 4) | (n & 15);
-  return g.offf[l] + (s * g.ntf[l] + t) * 64 + lane;
-}
+__host__ __device__ inline int wf_offset(const Geo& g, int l, int k, int n) { return g.offf[l] + frag_offset(g.ntf[l], k, n); }
 // float offset of W[k][n] of layer l in the backward-fragment image (operand element (row n, col k))
-__host__ __device__ inline int wb_offset(const Geo& g, int l, int k, int n) {
-  const int s = n >> 2, t = k >> 4, lane = ((n & 3) << 4) | (k & 15);
-  return g.offb[l] + (s * g.ntb[l] + t) * 64 + lane;
-}
+__host__ __device__ inline int wb_offset(const Geo& g, int l, int k, int n) { return g.offb[l] + frag_offset(g.ntb[l], n, k); }
 
 #ifdef __HIPCC__
 // ---------------------------------------------------------------- activations
@@ -108,10 +114,10 @@ __device__ __forceinline__ float sigmoid_ce(float x, float z) {
 
 // ---------------------------------------------------------------- network traits
 template <int KIND> struct NetT;
-template <> struct NetT<NET_ACTOR>  { static constexpr int A1 = ACT_RELU6, A2 = ACT_RELU6, A3 = ACT_RELU,  A4 = ACT_TANH,   NT3 = 1, L3 = 17; };
-template <> struct NetT<NET_CRITIC> { static constexpr int A1 = ACT_RELU6, A2 = ACT_RELU6, A3 = ACT_RELU,  A4 = ACT_LINEAR, NT3 = 1, L3 = 17; };
-template <> struct NetT<NET_GEN>    { static constexpr int A1 = ACT_RELU,  A2 = ACT_RELU,  A3 = ACT_RELU,  A4 = ACT_LINEAR, NT3 = 4, L3 = 65; };
-template <> struct NetT<NET_DISC>   { static constexpr int A1 = ACT_LRELU, A2 = ACT_LRELU, A3 = ACT_LRELU, A4 = ACT_LINEAR, NT3 = 1, L3 = 17; };
+template <> struct NetT<NET_ACTOR>  { static constexpr int A1 = ACT_RELU6, A2 = ACT_RELU6, A3 = ACT_RELU,  A4 = ACT_TANH,   NT3 = 1, L3 = 20; };
+template <> struct NetT<NET_CRITIC> { static constexpr int A1 = ACT_RELU6, A2 = ACT_RELU6, A3 = ACT_RELU,  A4 = ACT_LINEAR, NT3 = 1, L3 = 20; };
+template <> struct NetT<NET_GEN>    { static constexpr int A1 = ACT_RELU,  A2 = ACT_RELU,  A3 = ACT_RELU,  A4 = ACT_LINEAR, NT3 = 4, L3 = 68; };
+template <> struct NetT<NET_DISC>   { static constexpr int A1 = ACT_LRELU, A2 = ACT_LRELU, A3 = ACT_LRELU, A4 = ACT_LINEAR, NT3 = 1, L3 = 20; };
 
 // ---------------------------------------------------------------- LDS carve (floats)
 constexpr int PART_FLOATS = 4 * ROWS * 20;           // four waves' partial sums of one 16-column tile
@@ -119,9 +125,19 @@ constexpr int WIDE_FLOATS = ROWS * LD_W;
 constexpr int T3_FLOATS = ROWS * LD_3W;              // h3 tile (16 or 64 columns)
 constexpr int X0_FLOATS = ROWS * LD_X0;
 constexpr int O_FLOATS = ROWS * LD_O;
-constexpr int PIPE = 8;                              // k-steps of operands kept in flight per wave
+#ifndef RLGAN_GD
+#define RLGAN_GD 4
+#endif
+constexpr int GD = RLGAN_GD;                         // k-groups of operands kept in flight per wave
 
 __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+
+// Workgroup barrier for LDS hand-offs only: waits for this wave's LDS operations, not for its
+// outstanding global loads and stores (the activations written for the weight-gradient kernel are
+// not read again inside the launch, and weight loads requested ahead of time must stay in flight).
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 
 // Cycle stamps for diagnostic builds only (tools/stamp_probe.hip defines RLGAN_STAMP); in the library
 // build STAMP expands to nothing.
@@ -144,74 +160,100 @@ __device__ __forceinline__ void stamp_here(int tag) {
 #define STAMP(tag)
 #endif
 
-// Workgroup barrier for LDS hand-offs only: waits for this wave's LDS operations, not for its
-// outstanding global stores (the activations written for the weight-gradient kernel are not read
-// again inside the launch, so nothing here has to wait for them the way __syncthreads() does).
-__device__ __forceinline__ void lds_barrier() {
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
+// ---------------------------------------------------------------- weight fragments requested ahead
+// The B operands of the first groups of a layer (NT column tiles, NG k-groups): for the TPW tiles this
+// wave owns outright the first min(GD, NG) groups, for the NT%4 shared tiles all groups of this
+// wave's quarter of K.  issue() only starts the loads; nothing waits until dense16 consumes them.
+template <int NT, int NG>
+struct Pre {
+  static constexpr int TPW = NT / 4, REM = NT % 4;
+  static constexpr int D = NG < GD ? NG : GD;          // groups in flight for the owned tiles
+  static constexpr int MAXG = (NG + 3) / 4;            // groups per wave for the shared tiles
+  f32x4 bm[D][TPW > 0 ? TPW : 1];
+  f32x4 br[MAXG][REM > 0 ? REM : 1];
+  const float* wl;                                     // this lane's fragment address, owned tile 0, group 0
+  int g0, cnt;                                         // this wave's k-group range for the shared tiles
 
-// ---------------------------------------------------------------- MFMA product, software pipelined
-// acc[i] += X[16, 4*(s0..s1)] * fragment tile i, i < T.  `xrow` is this lane's A-operand address for
-// k-step 0 (LDS), `wl` this lane's B-operand address of tile 0 at k-step 0 (global, L2-resident),
-// consecutive tiles are 64 floats apart, consecutive k-steps `sstride` floats.  Operands of PIPE
-// k-steps are kept in flight.  The loop body is branch-free: the step count is rounded up to a
-// multiple of PIPE and the surplus steps multiply a zero activation by a re-read valid fragment.
-template <int T>
-__device__ __forceinline__ void mma_pipe(f32x4 (&acc)[T], const float* __restrict__ wl, int sstride,
-                                         const float* xrow, int s0, int s1) {
-  const int n = s1 - s0;
-  if (n <= 0) return;
-  const int nblk = (n + PIPE - 1) / PIPE;
-  const int last = s1 - 1;
-  float a[PIPE], b[PIPE][T];
+  __device__ __forceinline__ void issue(const float* __restrict__ wp) {
+    const int lane = threadIdx.x & 63, wave = wave_id();
+    wl = wp + ((wave * TPW) * 64 + lane) * 4;
+    g0 = (wave * NG) >> 2;
+    cnt = (((wave + 1) * NG) >> 2) - g0;
+    if constexpr (REM > 0) {
+      const float* wr = wp + ((4 * TPW) * 64 + lane) * 4;
 #pragma unroll
-  for (int j = 0; j < PIPE; ++j) {
-    const int s = s0 + j, sc = min(s, last);
-    const float av = xrow[4 * sc];
-    a[j] = s < s1 ? av : 0.f;
+      for (int j = 0; j < MAXG; ++j) {
+        const int gc = min(g0 + j, NG - 1);
 #pragma unroll
-    for (int i = 0; i < T; ++i) b[j][i] = wl[sc * sstride + i * 64];
-  }
-  for (int blk = 1; blk < nblk; ++blk) {
+        for (int i = 0; i < REM; ++i) br[j][i] = *(const f32x4*)(wr + (gc * NT + i) * 256);
+      }
+    }
+    if constexpr (TPW > 0) {
 #pragma unroll
-    for (int j = 0; j < PIPE; ++j) {
+      for (int g = 0; g < D; ++g) {
 #pragma unroll
-      for (int i = 0; i < T; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j][i], acc[i], 0, 0, 0);
-      const int s = s0 + blk * PIPE + j, sc = min(s, last);
-      const float av = xrow[4 * sc];
-      a[j] = s < s1 ? av : 0.f;
-#pragma unroll
-      for (int i = 0; i < T; ++i) b[j][i] = wl[sc * sstride + i * 64];
+        for (int i = 0; i < TPW; ++i) bm[g][i] = *(const f32x4*)(wl + (g * NT + i) * 256);
+      }
     }
   }
-#pragma unroll
-  for (int j = 0; j < PIPE; ++j) {
-#pragma unroll
-    for (int i = 0; i < T; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j][i], acc[i], 0, 0, 0);
-  }
-}
+};
 
-// One dense layer of a 16-row tile, Z[16, NT*16] = X * fragments, epilogue f(row, col, z) per element.
+struct NoPre { __device__ __forceinline__ float operator()(int, int) const { return 0.f; } };
+struct NoNext { __device__ __forceinline__ void operator()() const {} };
+
+// One dense layer of a 16-row tile, Z[16, NT*16] = X[16, NG*16] * fragments.
+//   p     the layer's weight fragments, already requested with p.issue()
+//   xs    the input tile in LDS (row stride ldx, at least NG*16 valid columns)
+//   pre   pre(row, col): a value the epilogue needs per output element (read before the MFMAs so its
+//         LDS latency hides behind them); NoPre when none is needed
+//   f     f(row, col, z, pre_value) -> value: the epilogue, once per output element (it writes LDS)
+//   gdst  when non-null, the returned values are also stored to this tile of a global work array laid
+//         out [column][16 rows] (one 16-byte store per lane and column for the dealt tiles)
+//   next  called between the last MFMA and the epilogue: the place to issue() the next layer's Pre
 // Of the NT column tiles, 4*(NT/4) are dealt to the four waves (NT/4 each, whole K range, epilogue
 // straight from the accumulators); the NT%4 left-over tiles are computed by all four waves together,
-// each taking a quarter of the K range, and their partial sums meet in LDS (`part`) where they are
-// added in wave order.  Ends with a workgroup barrier: afterwards every wave sees what f wrote.
-template <int NT, class F>
-__device__ __forceinline__ void dense16(const float* __restrict__ wp, int nsteps, const float* xs, int ldx,
-                                        float* part, F f) {
+// each taking a quarter of the k-groups, and their partial sums meet in LDS (`part`) where they are
+// added in wave order.  Starts and ends with a workgroup barrier on LDS.
+template <int NT, int NG, class P, class F, class X>
+__device__ __forceinline__ void dense16(Pre<NT, NG>& p, const float* xs, int ldx, float* part, P pre, F f, float* gdst, X next) {
   constexpr int TPW = NT / 4, REM = NT % 4, LDP = REM * 16 + 4;
+  constexpr int D = Pre<NT, NG>::D, MAXG = Pre<NT, NG>::MAXG;
   const int lane = threadIdx.x & 63, wave = wave_id();
-  const float* xrow = xs + (lane & 15) * ldx + (lane >> 4);
+  const int r0 = (lane >> 4) * 4, c0 = lane & 15;
+  const float* xq = xs + c0 * ldx + r0;                 // A operands of a group: one float4 at xq + 16*group
   STAMP(1);
+  float hv[TPW > 0 ? TPW : 1][4];
+  float hr[REM > 0 ? REM : 1];
+  if constexpr (TPW > 0) {
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) hv[i][r] = pre(r0 + r, 16 * (wave * TPW + i) + c0);
+    }
+  }
   if constexpr (REM > 0) {
-    const int per = (nsteps + 3) >> 2;
-    const int s0 = wave * per, s1 = min(nsteps, s0 + per);
+#pragma unroll
+    for (int i = 0; i < REM; ++i) hr[i] = pre((int)(threadIdx.x >> 4), 16 * (4 * TPW + i) + (int)(threadIdx.x & 15));
+  }
+  if constexpr (REM > 0) {
     f32x4 accr[REM];
 #pragma unroll
     for (int i = 0; i < REM; ++i) accr[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    mma_pipe<REM>(accr, wp + (4 * TPW) * 64 + lane, NT * 64, xrow, s0, s1);
-    float* pw = part + wave * ROWS * LDP + ((lane >> 4) * 4) * LDP + (lane & 15);
+    f32x4 ar[MAXG];
+#pragma unroll
+    for (int j = 0; j < MAXG; ++j) {
+      const f32x4 v = *(const f32x4*)(xq + 16 * min(p.g0 + j, NG - 1));
+      ar[j] = j < p.cnt ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int j = 0; j < MAXG; ++j) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+#pragma unroll
+        for (int i = 0; i < REM; ++i) accr[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[j][m], p.br[j][i][m], accr[i], 0, 0, 0);
+      }
+    }
+    float* pw = part + wave * ROWS * LDP + r0 * LDP + c0;
 #pragma unroll
     for (int i = 0; i < REM; ++i) {
 #pragma unroll
@@ -219,17 +261,42 @@ __device__ __forceinline__ void dense16(const float* __restrict__ wp, int nsteps
     }
   }
   STAMP(2);
+  f32x4 acc[TPW > 0 ? TPW : 1];
   if constexpr (TPW > 0) {
-    f32x4 acc[TPW];
 #pragma unroll
     for (int i = 0; i < TPW; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    mma_pipe<TPW>(acc, wp + (wave * TPW) * 64 + lane, NT * 64, xrow, 0, nsteps);
-    STAMP(3);
+    f32x4 am[D];
+#pragma unroll
+    for (int g = 0; g < D; ++g) am[g] = *(const f32x4*)(xq + 16 * g);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const int sl = g % D;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(am[sl][m], p.bm[sl][i][m], acc[i], 0, 0, 0);
+      }
+      if (g + D < NG) {
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) p.bm[sl][i] = *(const f32x4*)(p.wl + ((g + D) * NT + i) * 256);
+        am[sl] = *(const f32x4*)(xq + 16 * (g + D));
+      }
+      // keep the refill D groups ahead of its use: the scheduler would otherwise sink these loads next
+      // to their consumers to save registers, and the wave would wait out a full L2 round trip per group
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  STAMP(3);
+  next();
+  __builtin_amdgcn_sched_barrier(0);   // the next layer's requests stay ahead of this layer's epilogue
+  if constexpr (TPW > 0) {
 #pragma unroll
     for (int i = 0; i < TPW; ++i) {
-      const int col = 16 * (wave * TPW + i) + (lane & 15);
+      const int col = 16 * (wave * TPW + i) + c0;
+      f32x4 v;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) f((lane >> 4) * 4 + r, col, acc[i][r]);
+      for (int r = 0; r < 4; ++r) v[r] = f(r0 + r, col, acc[i][r], hv[i][r]);
+      if (gdst) *(f32x4*)(gdst + col * 16 + r0) = v;
     }
   }
   STAMP(4);
@@ -240,8 +307,10 @@ __device__ __forceinline__ void dense16(const float* __restrict__ wp, int nsteps
     constexpr int WS = ROWS * LDP;
 #pragma unroll
     for (int i = 0; i < REM; ++i) {
-      const float* p = part + row * LDP + 16 * i + col;
-      f(row, 16 * (4 * TPW + i) + col, ((p[0] + p[WS]) + p[2 * WS]) + p[3 * WS]);
+      const float* q = part + row * LDP + 16 * i + col;
+      const int cc = 16 * (4 * TPW + i) + col;
+      const float v = f(row, cc, ((q[0] + q[WS]) + q[2 * WS]) + q[3 * WS], hr[i]);
+      if (gdst) gdst[cc * 16 + row] = v;
     }
     STAMP(6);
     lds_barrier();
@@ -259,75 +328,89 @@ struct Tiles {
   float* part; // PART_FLOATS
 };
 
-// global work arrays of one network, already offset to this tile's first row (or all null)
+// global work arrays of one network, already offset to this 16-row tile (or all null).  Inside a
+// tile every array is laid out [column][16 rows], so that the weight-gradient kernel reads the
+// four batch rows an MFMA lane needs with one 16-byte load.
 struct ActsG {
   float* x0; float* h1; float* h2; float* h3; float* dz1; float* dz2; float* dz3; float* dz4;
 };
 
 // forward pass of a whole network for the tile in t.x0; activations stay in t.h1..t.out and, when
-// STORE, are also written to the global work arrays for the weight-gradient pass.
-template <int KIND, bool STORE>
-__device__ __forceinline__ void net_forward(const float* __restrict__ wf, const Geo& g, const Tiles& t, const ActsG& ws) {
+// STORE, are also written to the global work arrays for the weight-gradient pass.  `p1` holds the
+// first layer's fragments (issue()d by the caller, ideally well before); `next` is called before the
+// last layer's epilogue so the caller can request the fragments of whatever runs after this network.
+template <int KIND, bool STORE, class X>
+__device__ __forceinline__ void net_forward(const float* __restrict__ wf, const Geo& g, const Tiles& t, const ActsG& ws,
+                                            Pre<NT_H, 2>& p1, X next) {
   using N = NetT<KIND>;
-  constexpr int L3 = N::L3;
-  constexpr int NP3 = N::NT3 * 16;
+  constexpr int L3 = N::L3, NT3 = N::NT3;
   float* h1 = t.h1; float* h2 = t.h2; float* h3 = t.h3; float* out = t.out;
-  dense16<NT_H>(wf + g.offf[0], g.nsf[0], t.x0, LD_X0, t.part, [=](int r, int c, float z) {
+  Pre<NT_H, NT_H> p2;
+  dense16(p1, t.x0, LD_X0, t.part, NoPre{}, [=](int r, int c, float z, float) {
     const float v = c < HID ? act_f<N::A1>(z) : (c == HID ? 1.f : 0.f);
     h1[r * LD_W + c] = v;
-    if (STORE) ws.h1[r * NP_H + c] = v;
-  });
-  dense16<NT_H>(wf + g.offf[1], g.nsf[1], h1, LD_W, t.part, [=](int r, int c, float z) {
+    return v;
+  }, STORE ? ws.h1 : nullptr, [&] { p2.issue(wf + g.offf[1]); });
+  Pre<NT3, NT_H> p3;
+  dense16(p2, h1, LD_W, t.part, NoPre{}, [=](int r, int c, float z, float) {
     const float v = c < HID ? act_f<N::A2>(z) : (c == HID ? 1.f : 0.f);
     h2[r * LD_W + c] = v;
-    if (STORE) ws.h2[r * NP_H + c] = v;
-  });
+    return v;
+  }, STORE ? ws.h2 : nullptr, [&] { p3.issue(wf + g.offf[2]); });
   const int n3 = g.N3;
-  dense16<N::NT3>(wf + g.offf[2], g.nsf[2], h2, LD_W, t.part, [=](int r, int c, float z) {
+  Pre<1, NT3> p4;
+  dense16(p3, h2, LD_W, t.part, NoPre{}, [=](int r, int c, float z, float) {
     const float v = c < n3 ? act_f<N::A3>(z) : (c == n3 ? 1.f : 0.f);
     h3[r * L3 + c] = v;
-    if (STORE) ws.h3[r * NP3 + c] = v;
-  });
+    return v;
+  }, STORE ? ws.h3 : nullptr, [&] { p4.issue(wf + g.offf[3]); });
   const int nout = g.NOUT;
-  dense16<1>(wf + g.offf[3], g.nsf[3], h3, L3, t.part, [=](int r, int c, float z) {
-    out[r * LD_O + c] = c < nout ? act_f<N::A4>(z) : 0.f;
-  });
+  dense16(p4, h3, L3, t.part, NoPre{}, [=](int r, int c, float z, float) {
+    const float v = c < nout ? act_f<N::A4>(z) : 0.f;
+    out[r * LD_O + c] = v;
+    return v;
+  }, nullptr, next);
 }
 
 // backward pass: t.out must hold dL/dz4 ([16][LD_O], zeros beyond NOUT), t.h1..h3 the forward
-// activations.  Each layer's dz overwrites its activation tile in place and is written to the
-// global work arrays.  With NEED_DX0 the gradient w.r.t. the network inputs is left in t.x0
-// (columns 0..K0-1, stride LD_X0).
-template <int KIND, bool NEED_DX0, bool STORE>
-__device__ __forceinline__ void net_backward(const float* __restrict__ wb, const Geo& g, const Tiles& t, const ActsG& ws) {
+// activations.  Each layer's dz overwrites its activation tile in place and, when STORE, is written to
+// the global work arrays.  With NEED_DX0 the gradient w.r.t. the network inputs is left in t.x0
+// (columns 0..K0-1, stride LD_X0).  `p4` / `next` as in net_forward (p4 = fragments of W4^T).
+template <int KIND, bool NEED_DX0, bool STORE, class X>
+__device__ __forceinline__ void net_backward(const float* __restrict__ wb, const Geo& g, const Tiles& t, const ActsG& ws,
+                                             Pre<NetT<KIND>::NT3, 1>& p4, X next) {
   using N = NetT<KIND>;
-  constexpr int L3 = N::L3;
-  constexpr int NP3 = N::NT3 * 16;
+  constexpr int L3 = N::L3, NT3 = N::NT3;
   float* h1 = t.h1; float* h2 = t.h2; float* h3 = t.h3; float* x0 = t.x0;
   if (STORE) {
     const int r = threadIdx.x >> 4, c = threadIdx.x & 15;
-    ws.dz4[r * 16 + c] = t.out[r * LD_O + c];
+    ws.dz4[c * 16 + r] = t.out[r * LD_O + c];
   }
   const int n3 = g.N3;
-  dense16<N::NT3>(wb + g.offb[3], g.nsb[3], t.out, LD_O, t.part, [=](int r, int c, float z) {
-    const float v = c < n3 ? z * act_d<N::A3>(h3[r * L3 + c]) : 0.f;
+  Pre<NT_H, NT3> p3;
+  dense16(p4, t.out, LD_O, t.part, [=](int r, int c) { return h3[r * L3 + c]; }, [=](int r, int c, float z, float h) {
+    const float v = c < n3 ? z * act_d<N::A3>(h) : 0.f;
     h3[r * L3 + c] = v;
-    if (STORE) ws.dz3[r * NP3 + c] = v;
-  });
-  dense16<NT_H>(wb + g.offb[2], g.nsb[2], h3, L3, t.part, [=](int r, int c, float z) {
-    const float v = c < HID ? z * act_d<N::A2>(h2[r * LD_W + c]) : 0.f;
+    return v;
+  }, STORE ? ws.dz3 : nullptr, [&] { p3.issue(wb + g.offb[2]); });
+  Pre<NT_H, NT_H> p2;
+  dense16(p3, h3, L3, t.part, [=](int r, int c) { return h2[r * LD_W + c]; }, [=](int r, int c, float z, float h) {
+    const float v = c < HID ? z * act_d<N::A2>(h) : 0.f;
     h2[r * LD_W + c] = v;
-    if (STORE) ws.dz2[r * NP_H + c] = v;
-  });
-  dense16<NT_H>(wb + g.offb[1], g.nsb[1], h2, LD_W, t.part, [=](int r, int c, float z) {
-    const float v = c < HID ? z * act_d<N::A1>(h1[r * LD_W + c]) : 0.f;
+    return v;
+  }, STORE ? ws.dz2 : nullptr, [&] { p2.issue(wb + g.offb[1]); });
+  auto f1 = [=](int r, int c, float z, float h) {
+    const float v = c < HID ? z * act_d<N::A1>(h) : 0.f;
     h1[r * LD_W + c] = v;
-    if (STORE) ws.dz1[r * NP_H + c] = v;
-  });
-  if (NEED_DX0) {
-    dense16<1>(wb + g.offb[0], g.nsb[0], h1, LD_W, t.part, [=](int r, int c, float z) {
-      x0[r * LD_X0 + c] = z;
-    });
+    return v;
+  };
+  auto g1 = [=](int r, int c) { return h1[r * LD_W + c]; };
+  if constexpr (NEED_DX0) {
+    Pre<1, NT_H> p1;
+    dense16(p2, h2, LD_W, t.part, g1, f1, STORE ? ws.dz1 : nullptr, [&] { p1.issue(wb + g.offb[0]); });
+    dense16(p1, h1, LD_W, t.part, NoPre{}, [=](int r, int c, float z, float) { x0[r * LD_X0 + c] = z; return z; }, nullptr, next);
+  } else {
+    dense16(p2, h2, LD_W, t.part, g1, f1, STORE ? ws.dz1 : nullptr, next);
   }
 }
 
@@ -351,7 +434,7 @@ __device__ __forceinline__ void load_x0(float* x0, int row0, int n_rows, MatIn b
     }
     if (c == k0) v = 1.f;
     x0[r * LD_X0 + c] = v;
-    if (x0_global) x0_global[r * X0_COLS + c] = v;
+    if (x0_global) x0_global[c * 16 + r] = v;        // work arrays are [column][16 rows] per tile
   }
 }
 

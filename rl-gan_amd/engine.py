@@ -4,7 +4,8 @@ Sequence per minibatch (Curious_GAN.py:208-213):
     (1) critic.learn  (2) actor.learn  (3) discriminator.learn  (4) generator.learn
     (5) discriminator.eval  (6) generator.eval
 (1)->(2) and (3)->(4) are two independent chains, so the fused `update` runs them as two phases,
-{critic, D} then {actor, G}, each phase ending in ONE gradient exchange over a flat bucket.
+{critic, D} then {actor, G}: one launch per stage of a phase (row passes of both steps tile by
+tile, weight gradients, chunk reduction, optimizers) and ONE gradient exchange over a flat bucket.
 
 Data-parallel contract (no counterpart in the reference, which is single-process): every rank holds
 identical weights, computes gradients of its own shard with mean-type losses already divided by the
@@ -21,8 +22,8 @@ import torch
 
 from . import _lib
 from ._lib import check, lib
-from .core import (NULL_ACTS, NULL_NET, DeviceNet, Workspace, _stream, adam_apply, device, mat, ptr, rmsprop_apply,
-                   rows16, target_update, weight_grads)
+from .core import (NULL_ACTS, NULL_NET, DeviceNet, Workspace, _stream, adam_job, device, launch_apply, launch_reduce,
+                   launch_wgrads, mat, ptr, reduce_job, rmsprop_job, rows16, sum_parts, wgrad_job)
 
 
 class GradExchange:
@@ -144,110 +145,137 @@ class StepEngine:
     def _inv_gb(self, n_rows: int) -> float:
         return 1.0 / float(n_rows * self.exchange.world)
 
-    # ---- (1) critic.learn ---------------------------------------------------------------------
-    def critic_rows(self, C: CriticState, A: ActorState, s, a, r, s_):
+    # ---- argument records of the four row passes ---------------------------------------------------
+    def _critic_args(self, C: CriticState, A: ActorState, s, a, r, s_):
         n = s.shape[0]
         R = rows16(n)
         wc = self.workspace("c", C.e, R)
         wa = self.workspace("ca", A.e, R) if C.trains_actor else None
         lp = self.loss_parts("c", R // 16)
-        self._timed("critic_step_rows", lambda: check(lib.rlgan_critic_step_rows(
-            self.s_dim, self.a_dim, C.e.net(True), C.t.net(), A.t.net(), A.e.net(True) if C.trains_actor else NULL_NET,
-            mat(s), mat(a), mat(r), mat(s_), C.gamma, self._inv_gb(n), n,
-            wc.acts(), wa.acts() if wa is not None else NULL_ACTS, lp.data_ptr(), _stream()), "rlgan_critic_step_rows"))
-        return wc, wa, lp
+        args = _lib.CriticStep(self.s_dim, self.a_dim, n, C.e.net(True), C.t.net(), A.t.net(),
+                               A.e.net(True) if C.trains_actor else NULL_NET, mat(s), mat(a), mat(r), mat(s_),
+                               C.gamma, self._inv_gb(n), wc.acts(), wa.acts() if wa is not None else NULL_ACTS, lp.data_ptr())
+        return args, wc, wa, lp
 
-    def critic_grads(self, C, A, wc, wa, lp, n):
-        weight_grads(C.e, wc, lp, lp.numel(), self._inv_gb(n), self.losses[self.LOSS_CRITIC:], C.counter)
-        if wa is not None:
-            weight_grads(A.e, wa)
-
-    def critic_apply(self, C: CriticState, A: ActorState, wc, wa):
-        rmsprop_apply(C.e, wc.grad, C.ms, C.lr)
-        if wa is not None:
-            C.ensure_actor_slots(A.e.n_params)
-            rmsprop_apply(A.e, wa.grad, C.ms_actor, C.lr)
-        target_update(C.t, C.e, 1.0, C.counter, C.period)       # hard copy, DDPG.py:176-178
-
-    def critic_step(self, C, A, s, a, r, s_):
-        wc, wa, lp = self.critic_rows(C, A, s, a, r, s_)
-        self.critic_grads(C, A, wc, wa, lp, s.shape[0])
-        self.exchange.all_reduce_sum(wc.grad)
-        if wa is not None:
-            self.exchange.all_reduce_sum(wa.grad)
-        self.critic_apply(C, A, wc, wa)
-        return wc, wa
-
-    # ---- (2) actor.learn ----------------------------------------------------------------------
-    def actor_rows(self, A: ActorState, C: CriticState, s):
+    def _actor_args(self, A: ActorState, C: CriticState, s):
         n = s.shape[0]
         wa = self.workspace("a", A.e, rows16(n))
-        self._timed("actor_step_rows", lambda: check(lib.rlgan_actor_step_rows(
-            self.s_dim, self.a_dim, A.e.net(True), C.e.net(True), mat(s), n, wa.acts(), _stream()), "rlgan_actor_step_rows"))
-        return wa
+        return _lib.ActorStep(self.s_dim, self.a_dim, n, A.e.net(True), C.e.net(True), mat(s), wa.acts()), wa
 
-    def actor_apply(self, A: ActorState, wa):
-        rmsprop_apply(A.e, wa.grad, A.ms, -A.lr)                # RMSPropOptimizer(-lr): ascent, DDPG.py:112
-        target_update(A.t, A.e, 1.0, A.counter, A.period)       # DDPG.py:99-101
-
-    def actor_step(self, A, C, s):
-        wa = self.actor_rows(A, C, s)
-        weight_grads(A.e, wa, counter=A.counter)
-        self.exchange.all_reduce_sum(wa.grad)
-        self.actor_apply(A, wa)
-        return wa
-
-    # ---- (3) discriminator.learn --------------------------------------------------------------
-    def disc_rows(self, D: AdamState, g_data, s_, s, a, smooth: float = 0.0):
+    def _disc_args(self, D: AdamState, g_data, s_, s, a, smooth):
         n = s.shape[0]
         R = rows16(n)
         wd = self.workspace("d", D.net, 2 * R)
         lp = self.loss_parts("d", R // 16)
-        self._timed("disc_step_rows", lambda: check(lib.rlgan_disc_step_rows(
-            self.s_dim, self.a_dim, D.net.net(True), mat(s), mat(g_data), mat(a), mat(s_),
-            1.0 - smooth, self._inv_gb(n), n, wd.acts(), lp.data_ptr(), _stream()), "rlgan_disc_step_rows"))
-        return wd, lp
+        args = _lib.DiscStep(self.s_dim, self.a_dim, n, D.net.net(True), mat(s), mat(g_data), mat(a), mat(s_),
+                             1.0 - smooth, self._inv_gb(n), wd.acts(), lp.data_ptr())
+        return args, wd, lp
 
-    def disc_step(self, D, g_data, s_, s, a, smooth: float = 0.0):
-        wd, lp = self.disc_rows(D, g_data, s_, s, a, smooth)
-        weight_grads(D.net, wd, lp, lp.numel(), self._inv_gb(s.shape[0]), self.losses[self.LOSS_D_STEP:], D.step)
-        self.exchange.all_reduce_sum(wd.grad)
-        adam_apply(D.net, wd.grad, D.m, D.v, D.step, D.lr)
-        return wd
-
-    # ---- (4) generator.learn ------------------------------------------------------------------
-    def gen_rows(self, G: AdamState, D: AdamState, s, a):
+    def _gen_args(self, G: AdamState, D: AdamState, s, a):
         n = s.shape[0]
         R = rows16(n)
         wg = self.workspace("g", G.net, R)
         lp = self.loss_parts("g", R // 16)
-        self._timed("gen_step_rows", lambda: check(lib.rlgan_gen_step_rows(
-            self.s_dim, self.a_dim, G.net.net(True), D.net.net(True), mat(s), mat(a),
-            self._inv_gb(n), n, wg.acts(), lp.data_ptr(), _stream()), "rlgan_gen_step_rows"))
+        args = _lib.GenStep(self.s_dim, self.a_dim, n, G.net.net(True), D.net.net(True), mat(s), mat(a),
+                            self._inv_gb(n), wg.acts(), lp.data_ptr())
+        return args, wg, lp
+
+    # ---- job records ------------------------------------------------------------------------------
+    def _critic_jobs(self, C, A, wc, wa, lp, n):
+        wj = [wgrad_job(C.e, wc)]
+        rj = [reduce_job(C.e, wc, lp, lp.numel(), self._inv_gb(n), self.losses[self.LOSS_CRITIC:], C.counter)]
+        if wa is not None:
+            wj.append(wgrad_job(A.e, wa))
+            rj.append(reduce_job(A.e, wa))
+        return wj, rj
+
+    def _critic_apply_jobs(self, C, A, wc, wa):
+        # RMSProp on the critic, hard target copy on the period (DDPG.py:176-178); the actor eval net
+        # moves too when the critic's train-op reaches it (DDPG.py:148), with slots of its own
+        jobs = [rmsprop_job(C.e, wc.grad, C.ms, C.lr, target=C.t, tau=1.0, counter=C.counter, period=C.period)]
+        if wa is not None:
+            C.ensure_actor_slots(A.e.n_params)
+            jobs.append(rmsprop_job(A.e, wa.grad, C.ms_actor, C.lr))
+        return jobs
+
+    def _actor_apply_job(self, A, wa):
+        # RMSPropOptimizer(-lr): ascent (DDPG.py:112); hard target copy on the period (DDPG.py:99-101)
+        return rmsprop_job(A.e, wa.grad, A.ms, -A.lr, target=A.t, tau=1.0, counter=A.counter, period=A.period)
+
+    # ---- (1) critic.learn ---------------------------------------------------------------------
+    def critic_rows(self, C: CriticState, A: ActorState, s, a, r, s_):
+        args, wc, wa, lp = self._critic_args(C, A, s, a, r, s_)
+        self._timed("critic_step_rows", lambda: check(lib.rlgan_critic_step_rows(args, _stream()), "rlgan_critic_step_rows"))
+        return wc, wa, lp
+
+    def critic_step(self, C, A, s, a, r, s_):
+        wc, wa, lp = self.critic_rows(C, A, s, a, r, s_)
+        wj, rj = self._critic_jobs(C, A, wc, wa, lp, s.shape[0])
+        launch_wgrads(wj, self.s_dim, self.a_dim)
+        launch_reduce(rj)
+        self.exchange.all_reduce_sum(wc.grad)
+        if wa is not None:
+            self.exchange.all_reduce_sum(wa.grad)
+        launch_apply(self._critic_apply_jobs(C, A, wc, wa))
+        return wc, wa
+
+    # ---- (2) actor.learn ----------------------------------------------------------------------
+    def actor_rows(self, A: ActorState, C: CriticState, s):
+        args, wa = self._actor_args(A, C, s)
+        self._timed("actor_step_rows", lambda: check(lib.rlgan_actor_step_rows(args, _stream()), "rlgan_actor_step_rows"))
+        return wa
+
+    def actor_step(self, A, C, s):
+        wa = self.actor_rows(A, C, s)
+        launch_wgrads([wgrad_job(A.e, wa)], self.s_dim, self.a_dim)
+        launch_reduce([reduce_job(A.e, wa, counter=A.counter)])
+        self.exchange.all_reduce_sum(wa.grad)
+        launch_apply([self._actor_apply_job(A, wa)])
+        return wa
+
+    # ---- (3) discriminator.learn --------------------------------------------------------------
+    def disc_rows(self, D: AdamState, g_data, s_, s, a, smooth: float = 0.0):
+        args, wd, lp = self._disc_args(D, g_data, s_, s, a, smooth)
+        self._timed("disc_step_rows", lambda: check(lib.rlgan_disc_step_rows(args, _stream()), "rlgan_disc_step_rows"))
+        return wd, lp
+
+    def disc_step(self, D, g_data, s_, s, a, smooth: float = 0.0):
+        wd, lp = self.disc_rows(D, g_data, s_, s, a, smooth)
+        launch_wgrads([wgrad_job(D.net, wd)], self.s_dim, self.a_dim)
+        launch_reduce([reduce_job(D.net, wd, lp, lp.numel(), self._inv_gb(s.shape[0]), self.losses[self.LOSS_D_STEP:], D.step)])
+        self.exchange.all_reduce_sum(wd.grad)
+        launch_apply([adam_job(D.net, wd.grad, D.m, D.v, D.step, D.lr)])
+        return wd
+
+    # ---- (4) generator.learn ------------------------------------------------------------------
+    def gen_rows(self, G: AdamState, D: AdamState, s, a):
+        args, wg, lp = self._gen_args(G, D, s, a)
+        self._timed("gen_step_rows", lambda: check(lib.rlgan_gen_step_rows(args, _stream()), "rlgan_gen_step_rows"))
         return wg, lp
 
     def gen_step(self, G, D, s, a):
         wg, lp = self.gen_rows(G, D, s, a)
-        weight_grads(G.net, wg, lp, lp.numel(), self._inv_gb(s.shape[0]), self.losses[self.LOSS_G_STEP:], G.step)
+        launch_wgrads([wgrad_job(G.net, wg)], self.s_dim, self.a_dim)
+        launch_reduce([reduce_job(G.net, wg, lp, lp.numel(), self._inv_gb(s.shape[0]), self.losses[self.LOSS_G_STEP:], G.step)])
         self.exchange.all_reduce_sum(wg.grad)
-        adam_apply(G.net, wg.grad, G.m, G.v, G.step, G.lr)
+        launch_apply([adam_job(G.net, wg.grad, G.m, G.v, G.step, G.lr)])
         return wg
 
     # ---- (5)+(6) post-update losses -------------------------------------------------------------
     def gan_eval(self, G: AdamState, D: AdamState, g_data, s_, s, a, smooth: float = 0.0):
-        """Returns a device tensor [2] = (D_loss, G_loss) of this rank's shard, divided by the global
-        batch (summing over ranks gives the global means)."""
+        """D_loss and G_loss of this rank's shard, divided by the global batch (summing over ranks gives
+        the global means); returns the device view [2] of self.losses that receives them."""
         n = s.shape[0]
         nt = rows16(n) // 16
         lp = self.loss_parts("e", 2 * nt)
         self._timed("gan_eval_rows", lambda: check(lib.rlgan_gan_eval_rows(
             self.s_dim, self.a_dim, G.net.net(), D.net.net(), mat(s), mat(g_data), mat(a),
             mat(s_), 1.0 - smooth, n, lp.data_ptr(), _stream()), "rlgan_gan_eval_rows"))
-        out = lp.view(2, nt).sum(dim=1) * self._inv_gb(n)
-        self.losses[self.LOSS_D_EVAL:self.LOSS_D_EVAL + 2] = out
+        out = self.losses[self.LOSS_D_EVAL:self.LOSS_D_EVAL + 2]
+        sum_parts(lp, nt, 2, self._inv_gb(n), out)
         return out
 
-    # ---- fused update: two phases, one exchange each ------------------------------------------------
+    # ---- fused update: two phases, one launch per stage, one exchange per phase ---------------------
     def update(self, A: ActorState, C: CriticState, G: AdamState, D: AdamState, batch: torch.Tensor,
                smooth: float = 0.0, with_eval: bool = True, use_curious_reward: bool = True):
         """One reference update on a [B, 3S+A+2] fp32 batch in the 6-field replay layout
@@ -257,40 +285,33 @@ class StepEngine:
         b_s, b_s_, b_g = batch[:, :S], batch[:, S:2 * S], batch[:, 2 * S:3 * S]
         b_a = batch[:, 3 * S:3 * S + Ad]
         b_r = batch[:, 3 * S + Ad + (1 if use_curious_reward else 0)]
-        R = rows16(n)
         nc, na, nd, ng = C.e.n_params, A.e.n_params, D.net.n_params, G.net.n_params
-        cur = torch.cuda.current_stream()
-        side = self._side_stream()
-        # phase 1: critic step (main stream) and discriminator step (side stream) share the CUs
-        side.wait_stream(cur)
+        # phase 1: critic step and discriminator step, tile by tile in one launch
+        cargs, wc, wa, lpc = self._critic_args(C, A, b_s, b_a, b_r, b_s_)
+        dargs, wd, lpd = self._disc_args(D, b_g, b_s_, b_s, b_a, smooth)
         b1 = self.bucket("p1", nc + na + nd)
-        with torch.cuda.stream(side):
-            wd, lpd = self.disc_rows(D, b_g, b_s_, b_s, b_a, smooth)
-            wd.grad = b1[nc + na:]
-            weight_grads(D.net, wd, lpd, lpd.numel(), self._inv_gb(n), self.losses[self.LOSS_D_STEP:], D.step)
-        wc, wa, lpc = self.critic_rows(C, A, b_s, b_a, b_r, b_s_)
         wc.grad = b1[:nc]
         if wa is not None:
             wa.grad = b1[nc:nc + na]
-        self.critic_grads(C, A, wc, wa, lpc, n)
-        cur.wait_stream(side)
+        wd.grad = b1[nc + na:]
+        self._timed("phase1_rows", lambda: check(lib.rlgan_phase1_rows(cargs, dargs, _stream()), "rlgan_phase1_rows"))
+        wj, rj = self._critic_jobs(C, A, wc, wa, lpc, n)
+        launch_wgrads(wj + [wgrad_job(D.net, wd)], S, Ad)
+        launch_reduce(rj + [reduce_job(D.net, wd, lpd, lpd.numel(), self._inv_gb(n), self.losses[self.LOSS_D_STEP:], D.step)])
         self.exchange.all_reduce_sum(b1)
-        self.critic_apply(C, A, wc, wa)
-        adam_apply(D.net, wd.grad, D.m, D.v, D.step, D.lr)
+        launch_apply(self._critic_apply_jobs(C, A, wc, wa) + [adam_job(D.net, wd.grad, D.m, D.v, D.step, D.lr)])
         # phase 2: actor step and generator step (both read the nets phase 1 just updated)
-        side.wait_stream(cur)
+        aargs, wa2 = self._actor_args(A, C, b_s)
+        gargs, wg, lpg = self._gen_args(G, D, b_s, b_a)
         b2 = self.bucket("p2", na + ng)
-        with torch.cuda.stream(side):
-            wg, lpg = self.gen_rows(G, D, b_s, b_a)
-            wg.grad = b2[na:]
-            weight_grads(G.net, wg, lpg, lpg.numel(), self._inv_gb(n), self.losses[self.LOSS_G_STEP:], G.step)
-        wa2 = self.actor_rows(A, C, b_s)
         wa2.grad = b2[:na]
-        weight_grads(A.e, wa2, counter=A.counter)
-        cur.wait_stream(side)
+        wg.grad = b2[na:]
+        self._timed("phase2_rows", lambda: check(lib.rlgan_phase2_rows(aargs, gargs, _stream()), "rlgan_phase2_rows"))
+        launch_wgrads([wgrad_job(A.e, wa2), wgrad_job(G.net, wg)], S, Ad)
+        launch_reduce([reduce_job(A.e, wa2, counter=A.counter),
+                       reduce_job(G.net, wg, lpg, lpg.numel(), self._inv_gb(n), self.losses[self.LOSS_G_STEP:], G.step)])
         self.exchange.all_reduce_sum(b2)
-        self.actor_apply(A, wa2)
-        adam_apply(G.net, wg.grad, G.m, G.v, G.step, G.lr)
+        launch_apply([self._actor_apply_job(A, wa2), adam_job(G.net, wg.grad, G.m, G.v, G.step, G.lr)])
         if with_eval:
             self.gan_eval(G, D, b_g, b_s_, b_s, b_a, smooth)
 

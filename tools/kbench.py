@@ -55,6 +55,15 @@ def main():
         us = timeit(lambda: weight_grads(net, ws))
         tf = 2.0 * net.n_params * ws.rows / (us * 1e-6) / 1e12
         print(f"{name:22s} {us:8.1f} us  {tf:6.1f} TFLOP/s  (wpass + reduce)")
+    from rl_gan_amd._lib import check, lib
+    from rl_gan_amd.core import _stream
+    ca = e._critic_args(C, A, s, a, r, s_)[0]; da = e._disc_args(D, g, s_, s, a, 0.0)[0]
+    aa = e._actor_args(A, C, s)[0]; ga = e._gen_args(G, D, s, a)[0]
+    for name, fn in (("phase1_rows", lambda: check(lib.rlgan_phase1_rows(ca, da, _stream()))),
+                     ("phase2_rows", lambda: check(lib.rlgan_phase2_rows(aa, ga, _stream())))):
+        us = timeit(fn)
+        tf = 2.0 * MACS_PER_ROW[name] * B / (us * 1e-6) / 1e12
+        print(f"{name:22s} {us:8.1f} us  {tf:6.1f} TFLOP/s  {100 * tf / PEAK_FP32_TFLOPS:5.1f}% of fp32 peak")
     print(f"{'act step (rollout)':22s} {timeit(L.rollout_step):8.1f} us  (philox + act + autoreset)")
     print(f"{'sample + gather':22s} {timeit(lambda: L.memory.gather(L.memory.sample_indices(B, L.idx), L.batch)):8.1f} us")
     print(f"{'full update (eager)':22s} {timeit(L.update):8.1f} us")

@@ -19,19 +19,21 @@ __global__ __launch_bounds__(THREADS) void probe_kernel(const Args A) {
   t.part = b; b += PART_FLOATS; t.x0 = b; b += X0_FLOATS; t.h1 = b; b += WIDE_FLOATS; t.h2 = b; b += WIDE_FLOATS;
   t.h3 = b; b += T3_FLOATS; t.out = b;
   const int row0 = blockIdx.x * ROWS;
+  Pre<NT_H, 2> p1; p1.issue(A.wf + A.g.offf[0]);
   STAMP(100);
   load_x0(t.x0, row0, A.n_rows, MatIn{A.s, 7, 7, 0}, MatIn{nullptr, 0, 0, 0}, MatIn{nullptr, 0, 0, 0}, nullptr);
   __syncthreads();
   STAMP(101);
   const ActsG ws = acts_at((const float* const*)A.acts, row0, A.g.ld3);
-  net_forward<NET_ACTOR, true>(A.wf, A.g, t, ws);
+  Pre<1, 1> pb;
+  net_forward<NET_ACTOR, true>(A.wf, A.g, t, ws, p1, [&] { pb.issue(A.wb + A.g.offb[3]); });
   STAMP(102);
   {
     const int r = threadIdx.x >> 4, c = threadIdx.x & 15;
     t.out[r * LD_O + c] = c < 2 ? 0.01f * t.out[r * LD_O + c] : 0.f;
   }
   __syncthreads();
-  net_backward<NET_ACTOR, false, true>(A.wb, A.g, t, ws);
+  net_backward<NET_ACTOR, false, true>(A.wb, A.g, t, ws, pb, NoNext{});
   STAMP(103);
   __syncthreads();
   if (blockIdx.x == RLGAN_STAMP) {
