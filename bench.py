@@ -118,7 +118,8 @@ def main():
     losses = L.losses()
 
     if rank == 0:
-        avg_ms = {k: sum(v) / len(v) for k, v in times.items()}
+        # median over the eager pass: robust against the first launches (lazy work-array setup)
+        avg_ms = {k: sorted(v)[len(v) // 2] for k, v in times.items()}
         dom = max(avg_ms, key=avg_ms.get)
         flop = 2.0 * MACS_PER_ROW[dom] * BATCH
         achieved = flop / (avg_ms[dom] * 1e-3) / 1e12
