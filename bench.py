@@ -79,7 +79,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
@@ -87,8 +87,15 @@ def main():
     cfg = R.LearnerConfig(n_env=N_ENV, batch_size=BATCH, memory_capacity=CAPACITY, seed=1)
     L = R.CuriousLearner(cfg)
     L.fill()                                            # 257 acting steps: the ring must be full before learning
+    launch = "eager"
     if not args.eager:
-        L.capture()                                     # one iteration = one HIP graph replay
+        try:
+            L.capture()                                 # one iteration = one HIP graph replay
+            launch = "graph"
+        except Exception as e:                          # keep the run alive: same kernels, launched one by one
+            print(f"[bench] graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr, flush=True)
+            L._graph = None
+            torch.cuda.synchronize()
     for _ in range(args.warmup):
         L.step()
 
@@ -128,7 +135,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "curious_gan_ddpg_arm_b4096", "envs_per_gpu": N_ENV, "batch_per_gpu": BATCH,
-                       "replay_rows_per_gpu": CAPACITY, "global_batch": BATCH * world, "parallelism": f"dp{world}"},
+                       "replay_rows_per_gpu": CAPACITY, "global_batch": BATCH * world, "parallelism": f"dp{world}", "launch": launch},
             "env_steps_per_s": round(world * N_ENV * args.steps / dt, 1),
             "kernel_ms": {k: round(v, 4) for k, v in sorted(avg_ms.items())},
             "losses": {k: round(v, 6) for k, v in losses.items()},
@@ -138,7 +145,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -14,6 +14,7 @@ actor's policy gradient is a batch SUM in the reference (DDPG.py:109), so it is 
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass, field
 from typing import Dict, Optional, Tuple
 
@@ -33,14 +34,24 @@ class GradExchange:
     def __init__(self, group=None):
         import torch.distributed as dist
         self.dist = dist
-        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        up = dist.is_available() and dist.is_initialized()
+        # RLGAN_FORCE_EXCHANGE=1 keeps the collective in the step on a one-rank job (rehearsal of the
+        # multi-GPU launch sequence, graph capture included, on a single GPU)
+        self.enabled = up and (dist.get_world_size(group) > 1 or os.environ.get("RLGAN_FORCE_EXCHANGE") == "1")
         self.group = group
         self.world = dist.get_world_size(group) if self.enabled else 1
         self.rank = dist.get_rank(group) if self.enabled else 0
 
     def all_reduce_sum(self, bucket: torch.Tensor) -> None:
-        if self.enabled:
-            self.dist.all_reduce(bucket, op=self.dist.ReduceOp.SUM, group=self.group)
+        if not self.enabled:
+            return
+        if bucket.is_cuda and self.dist.get_backend(self.group) == "gloo":
+            # test rigs only (several ranks on one GPU): gloo moves the bucket through host memory
+            host = bucket.cpu()
+            self.dist.all_reduce(host, op=self.dist.ReduceOp.SUM, group=self.group)
+            bucket.copy_(host)
+            return
+        self.dist.all_reduce(bucket, op=self.dist.ReduceOp.SUM, group=self.group)
 
 
 @dataclass

@@ -177,7 +177,11 @@ class CuriousLearner:
             self.rollout_step()
 
     def losses(self) -> dict:
-        l = self.engine.losses.cpu().numpy()
+        """Losses of the last update as global-batch means.  Each rank holds its shard's sums divided
+        by the global batch, so with more than one rank this is a collective: call it on every rank."""
+        l = self.engine.losses.clone()
+        self.exchange.all_reduce_sum(l)
+        l = l.cpu().numpy()
         e = self.engine
         return {"critic": float(l[e.LOSS_CRITIC]), "D_step": float(l[e.LOSS_D_STEP]), "G_step": float(l[e.LOSS_G_STEP]),
                 "D_loss": float(l[e.LOSS_D_EVAL]), "G_loss": float(l[e.LOSS_G_EVAL])}
