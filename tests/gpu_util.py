@@ -14,6 +14,7 @@ from rl_gan_amd.core import DeviceNet
 from rl_gan_amd.engine import ActorState, AdamState, CriticState, StepEngine
 from oracle import nets as onets
 from oracle.agent import CuriousAgent, Hyper
+from oracle_util import load_weights, make_batch, make_oracle  # noqa: F401
 
 RTOL = 1e-5
 
@@ -39,21 +40,11 @@ def dev(x):
 class Pair:
     """An oracle agent (float64) and the device states with identical weights."""
 
-    def __init__(self, seed=1234, hyper=None, spread=True):
+    def __init__(self, seed=1234, hyper=None, spread=True, weights=None):
         self.hp = hyper or Hyper()
-        self.o = CuriousAgent(seed=seed, dtype=np.float64, hyper=self.hp)
-        if spread:
-            # make clipped / negative-side activations common so every mask branch is exercised
-            rng = np.random.RandomState(seed + 1)
-            for p in (self.o.actor_e, self.o.actor_t, self.o.critic_e, self.o.critic_t, self.o.gen, self.o.disc):
-                for k in p:
-                    if k.startswith("l1/") and p[k].shape[0] > 1:
-                        p[k] = p[k] * 6.0
-                    if "bias" in k or k.endswith("b1") or k.endswith("b3"):
-                        p[k] = p[k] + rng.uniform(-0.3, 0.3, p[k].shape)
-            self._round_all()
-        else:
-            self._round_all()
+        self.o = make_oracle(seed, self.hp, spread)
+        if weights is not None:
+            load_weights(self.o, weights)
         o = self.o
         mk = lambda kind, spec, params, train: DeviceNet(kind, 7, 2, trainable=train, init=onets.flatten(spec, params))
         self.A = ActorState(e=mk(_lib.NET_ACTOR, o.actor_spec, o.actor_e, True), t=mk(_lib.NET_ACTOR, o.actor_spec, o.actor_t, False),
@@ -64,12 +55,6 @@ class Pair:
         self.G = AdamState(net=mk(_lib.NET_GENERATOR, o.gen_spec, o.gen, True), lr=self.hp.lr_g)
         self.D = AdamState(net=mk(_lib.NET_DISCRIMINATOR, o.disc_spec, o.disc, True), lr=self.hp.lr_d)
         self.eng = StepEngine(7, 2)
-
-    def _round_all(self):
-        # the device holds fp32 weights: start the float64 oracle from the same representable values
-        for p in (self.o.actor_e, self.o.actor_t, self.o.critic_e, self.o.critic_t, self.o.gen, self.o.disc):
-            for k in p:
-                p[k] = p[k].astype(np.float32).astype(np.float64)
 
     def check_weights(self, what="", adam_steps=1):
         """Adam divides by sqrt(v): an entry whose gradient is rounding noise still moves by about
@@ -83,17 +68,3 @@ class Pair:
         close(self.C.t.get_flat(), o.flat("critic_t"), what=what + " critic_t")
         close(self.G.net.get_flat(), o.flat("gen"), what=what + " gen", atol=ad * self.hp.lr_g)
         close(self.D.net.get_flat(), o.flat("disc"), what=what + " disc", atol=ad * self.hp.lr_d)
-
-
-def make_batch(B, seed=0, f32=True):
-    """[B,25] rows in the 6-field layout with plausible ranges (states ~[-1.5,1.5], actions [-1,1])."""
-    rng = np.random.RandomState(seed)
-    b = np.empty((B, 25))
-    b[:, 0:21] = rng.uniform(-1.5, 1.5, (B, 21))
-    b[:, 0] = rng.randint(0, 2, B)
-    b[:, 21:23] = rng.uniform(-1, 1, (B, 2))
-    b[:, 23] = np.where(rng.rand(B) < 0.1, 10.0, 0.0)
-    b[:, 24] = b[:, 23] + 0.01 * rng.rand(B)
-    if f32:
-        b = b.astype(np.float32).astype(np.float64)
-    return b
