@@ -38,6 +38,7 @@ MACS_PER_ROW = {
     "disc_step_rows": 2 * (D + 42010),
     "gen_step_rows": G + 2 * D + 50350,
     "gan_eval_rows": 3 * D + G,
+    "rollout_eval_rows": 3 * D + G + A + G + D,       # losses of the update + acting step, one launch
 }
 MACS_PER_ROW["phase1_rows"] = MACS_PER_ROW["critic_step_rows"] + MACS_PER_ROW["disc_step_rows"]   # one launch, both steps
 MACS_PER_ROW["phase2_rows"] = MACS_PER_ROW["actor_step_rows"] + MACS_PER_ROW["gen_step_rows"]

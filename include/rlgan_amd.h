@@ -101,7 +101,11 @@ int rlgan_mlp_forward(int kind, int s_dim, int a_dim, rlgan_net_t net,
  * Each processes 16-row tiles of the minibatch: forward, loss, backward-to-inputs, and leaves the
  * per-layer inputs and pre-activation gradients in `acts` for rlgan_weight_grads.
  * `inv_global_batch` = 1 / (batch rows summed over all data-parallel ranks).
- * `loss_parts` receives one partial SUM per 16-row tile (n_tiles = ceil(n_rows/16)).           */
+ * `loss_parts` receives one partial SUM per 16-row tile (n_tiles = ceil(n_rows/16)).
+ * `row_idx` (device int64[n_rows], may be NULL): when given, minibatch row i of every input matrix of
+ * the step is read from row row_idx[i] of that matrix -- the matrices then point into the replay ring
+ * and the fancy-index copy of Memory.sample (Curious_GAN.py:169) needs no pass of its own.  Indices
+ * must lie inside the ring; they are not checked.                                              */
 
 /* Critic.learn DDPG.py:141-148,174-175: y = r + gamma*q'(s_, a'(s_)); L = mean (y-q(s,a))^2.
  * When `actor_eval.wf` is non-NULL the gradient is continued into the actor eval net with TanhGrad
@@ -113,6 +117,7 @@ typedef struct {
   float gamma, inv_global_batch;
   rlgan_acts_t acts_critic, acts_actor;
   float* loss_parts;
+  const int64_t* row_idx;
 } rlgan_critic_step_t;
 int rlgan_critic_step_rows(const rlgan_critic_step_t* step, void* stream);
 
@@ -122,6 +127,7 @@ typedef struct {
   rlgan_net_t actor_eval, critic_eval;
   rlgan_mat_t s;
   rlgan_acts_t acts_actor;
+  const int64_t* row_idx;
 } rlgan_actor_step_t;
 int rlgan_actor_step_rows(const rlgan_actor_step_t* step, void* stream);
 
@@ -134,6 +140,7 @@ typedef struct {
   float label_real, inv_global_batch;
   rlgan_acts_t acts_disc;
   float* loss_parts;
+  const int64_t* row_idx;
 } rlgan_disc_step_t;
 int rlgan_disc_step_rows(const rlgan_disc_step_t* step, void* stream);
 
@@ -145,6 +152,7 @@ typedef struct {
   float inv_global_batch;
   rlgan_acts_t acts_gen;
   float* loss_parts;
+  const int64_t* row_idx;
 } rlgan_gen_step_t;
 int rlgan_gen_step_rows(const rlgan_gen_step_t* step, void* stream);
 
@@ -155,11 +163,25 @@ int rlgan_gen_step_rows(const rlgan_gen_step_t* step, void* stream);
 int rlgan_phase1_rows(const rlgan_critic_step_t* critic, const rlgan_disc_step_t* disc, void* stream);
 int rlgan_phase2_rows(const rlgan_actor_step_t* actor, const rlgan_gen_step_t* gen, void* stream);
 
-/* Discriminator.eval + Generator.eval Curious_GAN.py:94-95,147-148 in one pass.
- * loss_parts: [2][n_tiles] -- D loss sums then G loss sums. */
-int rlgan_gan_eval_rows(int s_dim, int a_dim, rlgan_net_t gen, rlgan_net_t disc,
-                        rlgan_mat_t s, rlgan_mat_t g_stored, rlgan_mat_t a, rlgan_mat_t s_next,
-                        float label_real, int n_rows, float* loss_parts, void* stream);
+/* Discriminator.eval + Generator.eval Curious_GAN.py:94-95,147-148 in one launch (two workgroups
+ * per 16-row tile: D loss = fake + real pass, G loss = G then D).  loss_parts: [2][n_tiles] -- D loss
+ * sums then G loss sums.  Inputs: the matrices s, g_stored, a, s_next (through row_idx when given), or --
+ * when x0_disc and x0_gen are both non-NULL -- the input tiles (`acts.x0`) that rlgan_disc_step_rows
+ * and rlgan_gen_step_rows left for the same minibatch, which costs no gather and does not touch the
+ * replay ring (so an acting step may store into the ring in the same launch).  When loss_out is non-NULL the last workgroup to finish also writes
+ * loss_out[0..1] = loss_scale * totals (fixed summation order); that needs `ticket`, one device int32
+ * that is zero before the first launch using it (every launch leaves it zero again). */
+typedef struct {
+  int32_t s_dim, a_dim, n_rows;
+  rlgan_net_t gen, disc;
+  rlgan_mat_t s, g_stored, a, s_next;
+  float label_real, loss_scale;
+  float* loss_parts;
+  float* loss_out;
+  const int64_t* row_idx;
+  const float* x0_disc; const float* x0_gen;
+} rlgan_eval_t;
+int rlgan_gan_eval_rows(const rlgan_eval_t* eval, int32_t* ticket, void* stream);
 
 /* ---- weight gradients, reduction, optimizers ------------------------------------------------
  * Each call handles up to three (weight gradients) / four (reduce, apply) networks in one launch. */
@@ -255,16 +277,50 @@ int rlgan_philox_normal(float* out, int n_pairs, uint64_t seed, uint32_t stream_
 int rlgan_philox_uniform(double* out, int n_pairs, uint64_t seed, uint32_t stream_id, uint64_t index0,
                          const int64_t* step, int64_t step_mul, void* stream);
 
-/* ---- fused acting path for n_env environments (Curious_GAN.py:190-195) ------------------------
- * a = clip(actor(s) + var*noise, -1, 1); g = G(s, a); (s', r, done) = env.step(a);
+/* ---- fused acting path for n_env environments (Curious_GAN.py:190-198,222-234) -------------------
+ * a = clip(actor(s) + var*z, -1, 1); g = G(s, a); (s', r, done) = env.step(a);
  * curious_r = r + ita*(1 - D(s, a, g)); row = [s, s', g, a, r, curious_r] -> replay ring at
- * (pointer + env index) % capacity; s' is written back to state_f32 (the next step's input).
- * noise: [n,2] standard normal fp32 (NULL: no noise).  var is read from device memory.  When
- * pointer_dev (device int64) is non-NULL the ring position is read from it instead of `pointer`. */
-int rlgan_act_rows(int s_dim, int a_dim, rlgan_net_t actor_eval, rlgan_net_t gen, rlgan_net_t disc,
-                   rlgan_env_t env, int n_env, float* state_f32, const float* noise, const float* var,
-                   float ita, float* replay, int capacity, int dims, int ld_replay, int64_t pointer,
-                   const int64_t* pointer_dev, double* reward_out, uint8_t* done_out, void* stream);
+ * (pointer + env index) % capacity; then the episode cut: environment i is reset when done or
+ * ep_t[i] >= max_ep_steps-1 (ep_t[i] = 0), else ep_t[i] += 1; state_f32[i,:] receives the state the
+ * next step starts from.
+ *  z       : `noise` [n,2] standard normal fp32 when non-NULL; else, when rng_seed != 0, Philox stream 0
+ *            at counter step*n_env + i (what rlgan_philox_normal gives for the same key); else 0.
+ *  reset   : uniforms from `reset_u` [n,2] float64 when non-NULL, else Philox stream 1 at counter
+ *            n_env + step*n_env + i.  ep_t NULL: no episode cut.
+ *  counters: device int64[2] = {replay pointer, vector steps}; when non-NULL they replace `pointer` and
+ *            `step` and the last workgroup of the launch advances them by n_env and 1, which lets a
+ *            captured graph replay the loop.
+ *  var     : device float64 scalar.  When var_decay > 0 the last workgroup sets
+ *            var = max(var*var_decay, var_min) if the pointer after this step exceeds `capacity`
+ *            (`if M.pointer > MEMORY_CAPACITY`, Curious_GAN.py:197-198).
+ * `ticket` (see rlgan_gan_eval_rows) is required when counters is non-NULL or var_decay > 0. */
+typedef struct {
+  int32_t s_dim, a_dim, n_env;
+  rlgan_net_t actor_eval, gen, disc;
+  rlgan_env_t env;
+  float* state_f32;
+  const float* noise;
+  double* var;
+  float ita;
+  float* replay; int32_t capacity, dims, ld_replay;
+  int64_t pointer, step;
+  int64_t* counters;
+  double* reward_out; uint8_t* done_out;
+  uint64_t rng_seed;
+  int32_t* ep_t; int32_t max_ep_steps, mode_hard; const double* reset_u; int32_t* n_resets;
+  double var_decay, var_min;
+} rlgan_act_t;
+int rlgan_act_rows(const rlgan_act_t* act, int32_t* ticket, void* stream);
+
+/* np.random.choice(n_pop, size=n) as one extra workgroup of another launch (see rlgan_mt19937_choice). */
+typedef struct { uint32_t* mt_state; int64_t n_pop; int32_t n; int64_t* out_idx; } rlgan_sample_t;
+
+/* One launch for everything that only READS the networks between two updates: the loss evaluation of
+ * the update just done, the acting step that follows it, and the index draw for the next minibatch
+ * (any of the three may be NULL).  Acting and evaluation tiles are dealt round-robin so that every
+ * compute unit holds one of each. */
+int rlgan_rollout_eval_rows(const rlgan_act_t* act, const rlgan_eval_t* eval, const rlgan_sample_t* sample,
+                            int32_t* ticket, void* stream);
 
 #ifdef __cplusplus
 }

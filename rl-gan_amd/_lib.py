@@ -45,23 +45,46 @@ class CriticStep(C.Structure):
                 ("critic_eval", Net), ("critic_target", Net), ("actor_target", Net), ("actor_eval", Net),
                 ("s", Mat), ("a", Mat), ("r", Mat), ("s_next", Mat),
                 ("gamma", C.c_float), ("inv_global_batch", C.c_float),
-                ("acts_critic", Acts), ("acts_actor", Acts), ("loss_parts", _fp)]
+                ("acts_critic", Acts), ("acts_actor", Acts), ("loss_parts", _fp), ("row_idx", _fp)]
 
 
 class ActorStep(C.Structure):
     _fields_ = [("s_dim", _i32), ("a_dim", _i32), ("n_rows", _i32), ("actor_eval", Net), ("critic_eval", Net),
-                ("s", Mat), ("acts_actor", Acts)]
+                ("s", Mat), ("acts_actor", Acts), ("row_idx", _fp)]
 
 
 class DiscStep(C.Structure):
     _fields_ = [("s_dim", _i32), ("a_dim", _i32), ("n_rows", _i32), ("disc", Net),
                 ("s", Mat), ("g_stored", Mat), ("a", Mat), ("s_next", Mat),
-                ("label_real", C.c_float), ("inv_global_batch", C.c_float), ("acts_disc", Acts), ("loss_parts", _fp)]
+                ("label_real", C.c_float), ("inv_global_batch", C.c_float), ("acts_disc", Acts), ("loss_parts", _fp),
+                ("row_idx", _fp)]
 
 
 class GenStep(C.Structure):
     _fields_ = [("s_dim", _i32), ("a_dim", _i32), ("n_rows", _i32), ("gen", Net), ("disc", Net),
-                ("s", Mat), ("a", Mat), ("inv_global_batch", C.c_float), ("acts_gen", Acts), ("loss_parts", _fp)]
+                ("s", Mat), ("a", Mat), ("inv_global_batch", C.c_float), ("acts_gen", Acts), ("loss_parts", _fp),
+                ("row_idx", _fp)]
+
+
+class Eval(C.Structure):
+    _fields_ = [("s_dim", _i32), ("a_dim", _i32), ("n_rows", _i32), ("gen", Net), ("disc", Net),
+                ("s", Mat), ("g_stored", Mat), ("a", Mat), ("s_next", Mat),
+                ("label_real", C.c_float), ("loss_scale", C.c_float), ("loss_parts", _fp), ("loss_out", _fp),
+                ("row_idx", _fp), ("x0_disc", _fp), ("x0_gen", _fp)]
+
+
+class Act(C.Structure):
+    _fields_ = [("s_dim", _i32), ("a_dim", _i32), ("n_env", _i32), ("actor_eval", Net), ("gen", Net), ("disc", Net),
+                ("env", Env), ("state_f32", _fp), ("noise", _fp), ("var", _fp), ("ita", C.c_float),
+                ("replay", _fp), ("capacity", _i32), ("dims", _i32), ("ld_replay", _i32),
+                ("pointer", C.c_int64), ("step", C.c_int64), ("counters", _fp),
+                ("reward_out", _fp), ("done_out", _fp), ("rng_seed", C.c_uint64),
+                ("ep_t", _fp), ("max_ep_steps", _i32), ("mode_hard", _i32), ("reset_u", _fp), ("n_resets", _fp),
+                ("var_decay", C.c_double), ("var_min", C.c_double)]
+
+
+class Sample(C.Structure):
+    _fields_ = [("mt_state", _fp), ("n_pop", C.c_int64), ("n", _i32), ("out_idx", _fp)]
 
 
 class WgradJob(C.Structure):
@@ -108,7 +131,8 @@ PROTOTYPES = {
     "rlgan_gen_step_rows": [C.POINTER(GenStep), _vp],
     "rlgan_phase1_rows": [C.POINTER(CriticStep), C.POINTER(DiscStep), _vp],
     "rlgan_phase2_rows": [C.POINTER(ActorStep), C.POINTER(GenStep), _vp],
-    "rlgan_gan_eval_rows": [_i, _i, Net, Net, Mat, Mat, Mat, Mat, _f, _i, _vp, _vp],
+    "rlgan_gan_eval_rows": [C.POINTER(Eval), _vp, _vp],
+    "rlgan_rollout_eval_rows": [C.POINTER(Act), C.POINTER(Eval), C.POINTER(Sample), _vp, _vp],
     "rlgan_weight_grads": [C.POINTER(WgradJob), _i, _i, _i, _vp],
     "rlgan_grad_reduce": [C.POINTER(ReduceJob), _i, _vp],
     "rlgan_apply": [C.POINTER(ApplyJob), _i, _vp],
@@ -123,7 +147,7 @@ PROTOTYPES = {
     "rlgan_mt19937_choice": [_vp, _i64, _i, _vp, _vp],
     "rlgan_philox_normal": [_vp, _i, _u64, _u32, _u64, _vp, _i64, _vp],
     "rlgan_philox_uniform": [_vp, _i, _u64, _u32, _u64, _vp, _i64, _vp],
-    "rlgan_act_rows": [_i, _i, Net, Net, Net, Env, _i, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _i64, _vp, _vp, _vp, _vp],
+    "rlgan_act_rows": [C.POINTER(Act), _vp, _vp],
 }
 
 for _name, _args in PROTOTYPES.items():

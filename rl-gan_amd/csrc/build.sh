@@ -6,9 +6,9 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
 mkdir -p build
 $HIPCC $FLAGS -c learn_kernels.hip -o build/learn_kernels.o &
-$HIPCC $FLAGS -ffp-contract=off -c env_kernels.hip -o build/env_kernels.o &
+$HIPCC $FLAGS -c rollout_kernels.hip -o build/rollout_kernels.o &
 $HIPCC $FLAGS -c replay_kernels.hip -o build/replay_kernels.o &
 $HIPCC $FLAGS -c host_api.hip -o build/host_api.o &
 wait
-$HIPCC --offload-arch=gfx950 -shared -fPIC build/learn_kernels.o build/env_kernels.o build/replay_kernels.o build/host_api.o -o ../librlgan_amd.so
+$HIPCC --offload-arch=gfx950 -shared -fPIC build/learn_kernels.o build/rollout_kernels.o build/replay_kernels.o build/host_api.o -o ../librlgan_amd.so
 echo "built $(cd .. && pwd)/librlgan_amd.so"

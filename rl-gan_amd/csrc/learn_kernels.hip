@@ -1,55 +1,11 @@
 // Learner kernels: the four update steps of RL-GAN as 16-row-tile "row passes" (forward, loss,
 // backward-to-inputs), the batch-reduction "weight pass" (dW = X^T dZ), gradient reduction,
 // TF-1.x RMSProp / Adam and the target-network update.  gfx950 only.
-#include "rlgan_device.h"
-#include "rlgan_host.h"
+#include "rlgan_tiles.h"
 
 using namespace rlgan;
 
 namespace {
-
-struct NetP { const float* wf; const float* wb; };
-struct Mat { const float* p; int ld; };
-struct Acts8 { float* p[8]; };
-
-__device__ __forceinline__ MatIn gin(Mat m, int w) { return MatIn{m.p, m.ld, w, 0}; }
-__device__ __forceinline__ MatIn lin(const float* p, int ld, int w) { return MatIn{p, ld, w, 1}; }
-__device__ __forceinline__ MatIn nil() { return MatIn{nullptr, 0, 0, 0}; }
-
-struct TileSet { float* x0; float* h1; float* h2; float* h3; float* out; };
-
-__device__ __forceinline__ Tiles mk(const TileSet& s, float* part) { return Tiles{s.x0, s.h1, s.h2, s.h3, s.out, part}; }
-
-constexpr int SET_FLOATS = X0_FLOATS + 2 * WIDE_FLOATS + T3_FLOATS + O_FLOATS;
-
-__device__ __forceinline__ TileSet carve_set(float* base) {
-  TileSet s;
-  s.x0 = base; base += X0_FLOATS;
-  s.h1 = base; base += WIDE_FLOATS;
-  s.h2 = base; base += WIDE_FLOATS;
-  s.h3 = base; base += T3_FLOATS;
-  s.out = base;
-  return s;
-}
-
-// sum of v over the first 16 threads' values, returned to thread 0 (deterministic order)
-__device__ __forceinline__ float sum16_lds(float* scratch16, float v) {
-  if (threadIdx.x < ROWS) scratch16[threadIdx.x] = v;
-  __syncthreads();
-  float s = 0.f;
-  if (threadIdx.x == 0) {
-#pragma unroll
-    for (int i = 0; i < ROWS; ++i) s += scratch16[i];
-  }
-  __syncthreads();
-  return s;
-}
-
-// write a [16][16] "dz4" tile whose column 0..ncols-1 come from `vals16xN` in LDS, zeros elsewhere
-__device__ __forceinline__ void fill_out_col0(float* out, const float* v16) {
-  const int r = threadIdx.x >> 4, c = threadIdx.x & 15;
-  out[r * LD_O + c] = (c == 0) ? v16[r] : 0.f;
-}
 
 // ------------------------------------------------------------------------------------------
 // (1) critic step   DDPG.py:141-148,174-175
@@ -88,7 +44,7 @@ __device__ __forceinline__ void critic_tile(const CriticArgs& A, float* smem, in
   net_forward<NET_CRITIC, false>(A.critic_t.wf, A.gc, t, none, p_ct, [&] { p_ce.issue(A.critic_e.wf + A.gc.offf[0]); });
   if (threadIdx.x < ROWS) {
     const int gr = row0 + threadIdx.x;
-    const float rew = gr < A.n_rows ? A.r.p[(size_t)gr * A.r.ld] : 0.f;
+    const float rew = gr < A.n_rows ? mat_at(A.r, gr, 0) : 0.f;
     small[threadIdx.x] = rew + A.gamma * t.out[threadIdx.x * LD_O];      // y = R + gamma*q'  DDPG.py:142
   }
   // q = critic_eval(s, a)
@@ -117,7 +73,7 @@ __device__ __forceinline__ void critic_tile(const CriticArgs& A, float* smem, in
       const int gr = row0 + r;
       float v = 0.f;
       if (c < Ad && gr < A.n_rows) {
-        const float af = A.a.p[(size_t)gr * A.a.ld + c];
+        const float af = mat_at(A.a, gr, c);
         v = t.x0[r * LD_X0 + S + c] * (1.f - af * af);
       }
       dsave[r * LD_O + c] = v;
@@ -333,55 +289,6 @@ __global__ __launch_bounds__(THREADS) void phase2_kernel(const ActorArgs Aa, con
 }
 
 // ------------------------------------------------------------------------------------------
-// (5)+(6) D and G losses after both updates   Curious_GAN.py:94-95,147-148
-// ------------------------------------------------------------------------------------------
-struct EvalArgs {
-  Geo gg, gd;
-  NetP gen, disc;
-  Mat s, g, a, s_next;
-  float label_real;
-  int n_rows, n_tiles;
-  float* loss_parts;
-};
-
-__global__ __launch_bounds__(THREADS) void gan_eval_kernel(const EvalArgs A) {
-  __shared__ __attribute__((aligned(16))) float smem[PART_FLOATS + 2 * SET_FLOATS + 64];
-  float* part = smem;
-  const TileSet sg = carve_set(smem + PART_FLOATS);
-  const TileSet sd = carve_set(smem + PART_FLOATS + SET_FLOATS);
-  float* small = smem + PART_FLOATS + 2 * SET_FLOATS;
-  const Tiles tg = mk(sg, part), td = mk(sd, part);
-  const int row0 = blockIdx.x * ROWS;
-  const int S = A.gg.S, Ad = A.gg.A;
-  const ActsG none{};
-  Pre<NT_H, 2> p_d; p_d.issue(A.disc.wf + A.gd.offf[0]);
-  Pre<NT_H, 2> p_g;
-  auto d_loss = [&](const MatIn& xin, float label, auto next) -> float {
-    load_x0(td.x0, row0, A.n_rows, gin(A.s, S), xin, gin(A.a, Ad), nullptr);
-    __syncthreads();
-    net_forward<NET_DISC, false>(A.disc.wf, A.gd, td, none, p_d, next);
-    float l = 0.f;
-    if (threadIdx.x < ROWS && row0 + threadIdx.x < A.n_rows) l = sigmoid_ce(td.out[threadIdx.x * LD_O], label);
-    return sum16_lds(small, l);
-  };
-  float ld = d_loss(gin(A.g, S), 0.f, [&] { p_d.issue(A.disc.wf + A.gd.offf[0]); });
-  ld += d_loss(gin(A.s_next, S), A.label_real, [&] { p_g.issue(A.gen.wf + A.gg.offf[0]); });
-  load_x0(tg.x0, row0, A.n_rows, gin(A.s, S), gin(A.a, Ad), nil(), nullptr);
-  __syncthreads();
-  net_forward<NET_GEN, false>(A.gen.wf, A.gg, tg, none, p_g, [&] { p_d.issue(A.disc.wf + A.gd.offf[0]); });
-  load_x0(td.x0, row0, A.n_rows, gin(A.s, S), lin(tg.out, LD_O, S), gin(A.a, Ad), nullptr);
-  __syncthreads();
-  net_forward<NET_DISC, false>(A.disc.wf, A.gd, td, none, p_d, NoNext{});
-  float l = 0.f;
-  if (threadIdx.x < ROWS && row0 + threadIdx.x < A.n_rows) l = sigmoid_ce(td.out[threadIdx.x * LD_O], 1.f);
-  const float lg = sum16_lds(small, l);
-  if (threadIdx.x == 0) {
-    A.loss_parts[blockIdx.x] = ld;
-    A.loss_parts[A.n_tiles + blockIdx.x] = lg;
-  }
-}
-
-// ------------------------------------------------------------------------------------------
 // forward only (choose_action / predict / determine)
 // ------------------------------------------------------------------------------------------
 struct FwdArgs {
@@ -525,7 +432,7 @@ __device__ __forceinline__ void wpass_body(const WItem& it, int strip, int chunk
 }
 
 __global__ __launch_bounds__(THREADS) void wpass_kernel(const WArgs A) {
-  __shared__ __attribute__((aligned(16))) float part[PART_FLOATS];
+  __shared__ __attribute__((aligned(16))) float part[4 * ROWS * 20];   // four waves' partial sums of one 16-column tile
   int item = 0;
 #pragma unroll
   for (int i = 1; i < MAX_WITEMS; ++i) if (i < A.n_items && (int)blockIdx.x >= A.it[i].blk0) item = i;
@@ -666,19 +573,6 @@ __global__ void pack_kernel(const float* __restrict__ canon, int n, const int32_
   if (wb) { const int ob = map_b[p]; if (ob >= 0) wb[ob] = w; }
 }
 
-inline Mat M(rlgan_mat_t m) { return Mat{m.p, m.ld}; }
-inline NetP NP(rlgan_net_t n) { return NetP{n.wf, n.wb}; }
-inline Acts8 A8(const rlgan_acts_t& a) {
-  Acts8 r;
-  r.p[0] = a.x0; r.p[1] = a.h1; r.p[2] = a.h2; r.p[3] = a.h3;
-  r.p[4] = a.dz1; r.p[5] = a.dz2; r.p[6] = a.dz3; r.p[7] = a.dz4;
-  return r;
-}
-inline bool acts_ok(const rlgan_acts_t& a) {
-  return a.x0 && a.h1 && a.h2 && a.h3 && a.dz1 && a.dz2 && a.dz3 && a.dz4;
-}
-inline int launched() { return (int)hipGetLastError(); }
-
 // ---- argument validation / packing shared by the single-step and the fused-phase entry points
 int make_critic_args(CriticArgs& A, const rlgan_critic_step_t* c) {
   if (!c) return RLGAN_E_ARG;
@@ -688,7 +582,7 @@ int make_critic_args(CriticArgs& A, const rlgan_critic_step_t* c) {
   A.train_actor = c->actor_eval.wf != nullptr;
   if (A.train_actor && (!c->actor_eval.wb || !acts_ok(c->acts_actor))) return RLGAN_E_ARG;
   A.critic_e = NP(c->critic_eval); A.critic_t = NP(c->critic_target); A.actor_t = NP(c->actor_target); A.actor_e = NP(c->actor_eval);
-  A.s = M(c->s); A.a = M(c->a); A.r = M(c->r); A.s_next = M(c->s_next);
+  A.s = M(c->s, c->row_idx); A.a = M(c->a, c->row_idx); A.r = M(c->r, c->row_idx); A.s_next = M(c->s_next, c->row_idx);
   A.gamma = c->gamma; A.inv_gb = c->inv_global_batch; A.n_rows = c->n_rows;
   A.acts_c = A8(c->acts_critic); A.acts_a = A8(c->acts_actor); A.loss_parts = c->loss_parts;
   return 0;
@@ -698,7 +592,7 @@ int make_actor_args(ActorArgs& A, const rlgan_actor_step_t* c) {
   if (!make_geo(NET_CRITIC, c->s_dim, c->a_dim, A.gc) || !make_geo(NET_ACTOR, c->s_dim, c->a_dim, A.ga)) return RLGAN_E_DIMS;
   if (c->n_rows <= 0 || !c->actor_eval.wf || !c->actor_eval.wb || !c->critic_eval.wf || !c->critic_eval.wb || !c->s.p ||
       !acts_ok(c->acts_actor)) return RLGAN_E_ARG;
-  A.actor_e = NP(c->actor_eval); A.critic_e = NP(c->critic_eval); A.s = M(c->s); A.n_rows = c->n_rows; A.acts_a = A8(c->acts_actor);
+  A.actor_e = NP(c->actor_eval); A.critic_e = NP(c->critic_eval); A.s = M(c->s, c->row_idx); A.n_rows = c->n_rows; A.acts_a = A8(c->acts_actor);
   return 0;
 }
 int make_disc_args(DiscArgs& A, const rlgan_disc_step_t* c) {
@@ -706,7 +600,7 @@ int make_disc_args(DiscArgs& A, const rlgan_disc_step_t* c) {
   if (!make_geo(NET_DISC, c->s_dim, c->a_dim, A.gd)) return RLGAN_E_DIMS;
   if (c->n_rows <= 0 || !c->disc.wf || !c->disc.wb || !c->s.p || !c->g_stored.p || !c->a.p || !c->s_next.p || !c->loss_parts ||
       !acts_ok(c->acts_disc)) return RLGAN_E_ARG;
-  A.disc = NP(c->disc); A.s = M(c->s); A.g = M(c->g_stored); A.a = M(c->a); A.s_next = M(c->s_next);
+  A.disc = NP(c->disc); A.s = M(c->s, c->row_idx); A.g = M(c->g_stored, c->row_idx); A.a = M(c->a, c->row_idx); A.s_next = M(c->s_next, c->row_idx);
   A.label_real = c->label_real; A.inv_gb = c->inv_global_batch; A.n_rows = c->n_rows; A.rows16 = cdiv(c->n_rows, ROWS) * ROWS;
   A.acts_d = A8(c->acts_disc); A.loss_parts = c->loss_parts;
   return 0;
@@ -716,7 +610,7 @@ int make_gen_args(GenArgs& A, const rlgan_gen_step_t* c) {
   if (!make_geo(NET_GEN, c->s_dim, c->a_dim, A.gg) || !make_geo(NET_DISC, c->s_dim, c->a_dim, A.gd)) return RLGAN_E_DIMS;
   if (c->n_rows <= 0 || !c->gen.wf || !c->gen.wb || !c->disc.wf || !c->disc.wb || !c->s.p || !c->a.p || !c->loss_parts ||
       !acts_ok(c->acts_gen)) return RLGAN_E_ARG;
-  A.gen = NP(c->gen); A.disc = NP(c->disc); A.s = M(c->s); A.a = M(c->a); A.inv_gb = c->inv_global_batch; A.n_rows = c->n_rows;
+  A.gen = NP(c->gen); A.disc = NP(c->disc); A.s = M(c->s, c->row_idx); A.a = M(c->a, c->row_idx); A.inv_gb = c->inv_global_batch; A.n_rows = c->n_rows;
   A.acts_g = A8(c->acts_gen); A.loss_parts = c->loss_parts;
   return 0;
 }
@@ -774,18 +668,6 @@ int rlgan_phase2_rows(const rlgan_actor_step_t* a, const rlgan_gen_step_t* g, vo
   return launched();
 }
 
-int rlgan_gan_eval_rows(int s_dim, int a_dim, rlgan_net_t gen, rlgan_net_t disc,
-                        rlgan_mat_t s, rlgan_mat_t g_stored, rlgan_mat_t a, rlgan_mat_t s_next,
-                        float label_real, int n_rows, float* loss_parts, void* stream) {
-  EvalArgs A;
-  if (!make_geo(NET_GEN, s_dim, a_dim, A.gg) || !make_geo(NET_DISC, s_dim, a_dim, A.gd)) return RLGAN_E_DIMS;
-  if (n_rows <= 0 || !gen.wf || !disc.wf || !s.p || !g_stored.p || !a.p || !s_next.p || !loss_parts) return RLGAN_E_ARG;
-  A.gen = NP(gen); A.disc = NP(disc); A.s = M(s); A.g = M(g_stored); A.a = M(a); A.s_next = M(s_next);
-  A.label_real = label_real; A.n_rows = n_rows; A.n_tiles = cdiv(n_rows, ROWS); A.loss_parts = loss_parts;
-  hipLaunchKernelGGL(gan_eval_kernel, dim3(A.n_tiles), dim3(THREADS), 0, (hipStream_t)stream, A);
-  return launched();
-}
-
 int rlgan_mlp_forward(int kind, int s_dim, int a_dim, rlgan_net_t net,
                       rlgan_mat_t s, rlgan_mat_t x, rlgan_mat_t a,
                       float* out, int ld_out, int out_mode, int n_rows, void* stream) {
@@ -795,7 +677,7 @@ int rlgan_mlp_forward(int kind, int s_dim, int a_dim, rlgan_net_t net,
   if (n_rows <= 0 || !net.wf || !s.p || !out || ld_out < A.g.NOUT || out_mode < 0 || out_mode > 2) return RLGAN_E_ARG;
   if (kind != NET_ACTOR && !a.p) return RLGAN_E_ARG;
   if (kind == NET_DISC && !x.p) return RLGAN_E_ARG;
-  A.net = NP(net); A.s = M(s); A.x = M(x); A.a = M(a); A.out = out; A.ld_out = ld_out; A.out_mode = out_mode; A.n_rows = n_rows;
+  A.net = NP(net); A.s = M(s, nullptr); A.x = M(x, nullptr); A.a = M(a, nullptr); A.out = out; A.ld_out = ld_out; A.out_mode = out_mode; A.n_rows = n_rows;
   const dim3 grid(cdiv(n_rows, ROWS)), block(THREADS);
   hipStream_t st = (hipStream_t)stream;
   switch (kind) {

@@ -10,7 +10,7 @@
 // one 16-byte load per lane brings the B operands of four consecutive MFMAs of a tile, one
 // ds_read_b128 their A operands; GD groups are kept in flight and the first GD groups of the NEXT
 // layer are requested before the current layer's epilogue, so the L2/Infinity-Cache latency of the
-// weight stream hides behind arithmetic.  Tiles left over after the deal split K over the waves.
+// weight stream hides behind arithmetic.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -120,7 +120,7 @@ template <> struct NetT<NET_GEN>    { static constexpr int A1 = ACT_RELU,  A2 = 
 template <> struct NetT<NET_DISC>   { static constexpr int A1 = ACT_LRELU, A2 = ACT_LRELU, A3 = ACT_LRELU, A4 = ACT_LINEAR, NT3 = 1, L3 = 20; };
 
 // ---------------------------------------------------------------- LDS carve (floats)
-constexpr int PART_FLOATS = 4 * ROWS * 20;           // four waves' partial sums of one 16-column tile
+constexpr int PART_FLOATS = 0;                       // (no partial-sum staging: every tile belongs to one wave)
 constexpr int WIDE_FLOATS = ROWS * LD_W;
 constexpr int T3_FLOATS = ROWS * LD_3W;              // h3 tile (16 or 64 columns)
 constexpr int X0_FLOATS = ROWS * LD_X0;
@@ -161,45 +161,94 @@ __device__ __forceinline__ void stamp_here(int tag) {
 #endif
 
 // ---------------------------------------------------------------- weight fragments requested ahead
-// The B operands of the first groups of a layer (NT column tiles, NG k-groups): for the TPW tiles this
-// wave owns outright the first min(GD, NG) groups, for the NT%4 shared tiles all groups of this
-// wave's quarter of K.  issue() only starts the loads; nothing waits until dense16 consumes them.
+// Column tiles of a layer are dealt to the four waves round-robin: the wave with rotated index w owns
+// tiles w, w+4, w+8, ...  (NT%4 waves own one tile more than the others; with fewer than four tiles
+// some waves own none and only wait at the layer's barrier).  The rotation differs per workgroup so
+// that the busier waves of workgroups sharing a compute unit land on different SIMDs.
+// Pre holds the B operands of the first min(GD, NG) k-groups of this wave's tiles: issue() only starts
+// the loads; nothing waits until dense16 consumes them.
 template <int NT, int NG>
 struct Pre {
-  static constexpr int TPW = NT / 4, REM = NT % 4;
-  static constexpr int D = NG < GD ? NG : GD;          // groups in flight for the owned tiles
-  static constexpr int MAXG = (NG + 3) / 4;            // groups per wave for the shared tiles
-  f32x4 bm[D][TPW > 0 ? TPW : 1];
-  f32x4 br[MAXG][REM > 0 ? REM : 1];
-  const float* wl;                                     // this lane's fragment address, owned tile 0, group 0
-  int g0, cnt;                                         // this wave's k-group range for the shared tiles
+  static constexpr int TMAX = (NT + 3) / 4, TMIN = NT / 4, NHEAVY = NT % 4;
+  static constexpr int D = NG < GD ? NG : GD;          // groups in flight
+  f32x4 b[D][TMAX];
+  const float* wl;                                     // this lane's fragment address: own tile 0, group 0
+  int w;                                               // rotated wave index
 
+  template <int T>
+  __device__ __forceinline__ void load_first() {
+#pragma unroll
+    for (int g = 0; g < D; ++g) {
+#pragma unroll
+      for (int i = 0; i < T; ++i) b[g][i] = *(const f32x4*)(wl + (g * NT + 4 * i) * 256);
+    }
+  }
   __device__ __forceinline__ void issue(const float* __restrict__ wp) {
-    const int lane = threadIdx.x & 63, wave = wave_id();
-    wl = wp + ((wave * TPW) * 64 + lane) * 4;
-    g0 = (wave * NG) >> 2;
-    cnt = (((wave + 1) * NG) >> 2) - g0;
-    if constexpr (REM > 0) {
-      const float* wr = wp + ((4 * TPW) * 64 + lane) * 4;
-#pragma unroll
-      for (int j = 0; j < MAXG; ++j) {
-        const int gc = min(g0 + j, NG - 1);
-#pragma unroll
-        for (int i = 0; i < REM; ++i) br[j][i] = *(const f32x4*)(wr + (gc * NT + i) * 256);
-      }
-    }
-    if constexpr (TPW > 0) {
-#pragma unroll
-      for (int g = 0; g < D; ++g) {
-#pragma unroll
-        for (int i = 0; i < TPW; ++i) bm[g][i] = *(const f32x4*)(wl + (g * NT + i) * 256);
-      }
-    }
+    const int lane = threadIdx.x & 63;
+    w = (wave_id() + (int)blockIdx.x) & 3;
+    wl = wp + (w * 64 + lane) * 4;
+    if constexpr (NHEAVY == 0) load_first<TMAX>();
+    else if (w < NHEAVY) load_first<TMAX>();
+    else if constexpr (TMIN > 0) load_first<TMIN>();
   }
 };
 
 struct NoPre { __device__ __forceinline__ float operator()(int, int) const { return 0.f; } };
 struct NoNext { __device__ __forceinline__ void operator()() const {} };
+
+// The share of one wave in a dense layer: T column tiles over the whole K range.
+template <int NT, int NG, int T, class P, class F, class X>
+__device__ __forceinline__ void dense_tiles(Pre<NT, NG>& p, const float* xq, int r0, int c0, P pre, F f, float* gdst, X next) {
+  constexpr int D = Pre<NT, NG>::D;
+  constexpr int KC = (T == 1 && NG >= 4) ? 4 : 1;      // a lone tile splits K over independent accumulation chains
+  float hv[T][4];
+#pragma unroll
+  for (int i = 0; i < T; ++i) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) hv[i][r] = pre(r0 + r, 16 * (p.w + 4 * i) + c0);
+  }
+  f32x4 acc[T][KC];
+#pragma unroll
+  for (int i = 0; i < T; ++i) {
+#pragma unroll
+    for (int k = 0; k < KC; ++k) acc[i][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  f32x4 am[D];
+#pragma unroll
+  for (int g = 0; g < D; ++g) am[g] = *(const f32x4*)(xq + 16 * g);
+  STAMP(2);
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    const int sl = g % D;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+#pragma unroll
+      for (int i = 0; i < T; ++i)
+        acc[i][g % KC] = __builtin_amdgcn_mfma_f32_16x16x4f32(am[sl][m], p.b[sl][i][m], acc[i][g % KC], 0, 0, 0);
+    }
+    if (g + D < NG) {
+#pragma unroll
+      for (int i = 0; i < T; ++i) p.b[sl][i] = *(const f32x4*)(p.wl + ((g + D) * NT + 4 * i) * 256);
+      am[sl] = *(const f32x4*)(xq + 16 * (g + D));
+    }
+    // keep the refill D groups ahead of its use: the scheduler would otherwise sink these loads next
+    // to their consumers to save registers, and the wave would wait out a full L2 round trip per group
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  STAMP(3);
+  next();
+  __builtin_amdgcn_sched_barrier(0);   // the next layer's requests stay ahead of this layer's epilogue
+#pragma unroll
+  for (int i = 0; i < T; ++i) {
+    const int col = 16 * (p.w + 4 * i) + c0;
+    f32x4 z = acc[i][0];
+    if constexpr (KC == 4) z = ((acc[i][0] + acc[i][1]) + acc[i][2]) + acc[i][3];
+    f32x4 v;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = f(r0 + r, col, z[r], hv[i][r]);
+    if (gdst) *(f32x4*)(gdst + col * 16 + r0) = v;
+  }
+}
 
 // One dense layer of a 16-row tile, Z[16, NT*16] = X[16, NG*16] * fragments.
 //   p     the layer's weight fragments, already requested with p.issue()
@@ -208,114 +257,27 @@ struct NoNext { __device__ __forceinline__ void operator()() const {} };
 //         LDS latency hides behind them); NoPre when none is needed
 //   f     f(row, col, z, pre_value) -> value: the epilogue, once per output element (it writes LDS)
 //   gdst  when non-null, the returned values are also stored to this tile of a global work array laid
-//         out [column][16 rows] (one 16-byte store per lane and column for the dealt tiles)
-//   next  called between the last MFMA and the epilogue: the place to issue() the next layer's Pre
-// Of the NT column tiles, 4*(NT/4) are dealt to the four waves (NT/4 each, whole K range, epilogue
-// straight from the accumulators); the NT%4 left-over tiles are computed by all four waves together,
-// each taking a quarter of the k-groups, and their partial sums meet in LDS (`part`) where they are
-// added in wave order.  Starts and ends with a workgroup barrier on LDS.
+//         out [column][16 rows] (one 16-byte store per lane and column)
+//   next  called by every wave between its last MFMA and its epilogue: the place to issue() the next
+//         layer's Pre
+// Ends with a workgroup barrier on LDS (what the epilogues wrote is visible to every wave after it).
 template <int NT, int NG, class P, class F, class X>
-__device__ __forceinline__ void dense16(Pre<NT, NG>& p, const float* xs, int ldx, float* part, P pre, F f, float* gdst, X next) {
-  constexpr int TPW = NT / 4, REM = NT % 4, LDP = REM * 16 + 4;
-  constexpr int D = Pre<NT, NG>::D, MAXG = Pre<NT, NG>::MAXG;
-  const int lane = threadIdx.x & 63, wave = wave_id();
+__device__ __forceinline__ void dense16(Pre<NT, NG>& p, const float* xs, int ldx, float*, P pre, F f, float* gdst, X next) {
+  using Q = Pre<NT, NG>;
+  const int lane = threadIdx.x & 63;
   const int r0 = (lane >> 4) * 4, c0 = lane & 15;
   const float* xq = xs + c0 * ldx + r0;                 // A operands of a group: one float4 at xq + 16*group
   STAMP(1);
-  float hv[TPW > 0 ? TPW : 1][4];
-  float hr[REM > 0 ? REM : 1];
-  if constexpr (TPW > 0) {
-#pragma unroll
-    for (int i = 0; i < TPW; ++i) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) hv[i][r] = pre(r0 + r, 16 * (wave * TPW + i) + c0);
-    }
-  }
-  if constexpr (REM > 0) {
-#pragma unroll
-    for (int i = 0; i < REM; ++i) hr[i] = pre((int)(threadIdx.x >> 4), 16 * (4 * TPW + i) + (int)(threadIdx.x & 15));
-  }
-  if constexpr (REM > 0) {
-    f32x4 accr[REM];
-#pragma unroll
-    for (int i = 0; i < REM; ++i) accr[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 ar[MAXG];
-#pragma unroll
-    for (int j = 0; j < MAXG; ++j) {
-      const f32x4 v = *(const f32x4*)(xq + 16 * min(p.g0 + j, NG - 1));
-      ar[j] = j < p.cnt ? v : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-#pragma unroll
-    for (int j = 0; j < MAXG; ++j) {
-#pragma unroll
-      for (int m = 0; m < 4; ++m) {
-#pragma unroll
-        for (int i = 0; i < REM; ++i) accr[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[j][m], p.br[j][i][m], accr[i], 0, 0, 0);
-      }
-    }
-    float* pw = part + wave * ROWS * LDP + r0 * LDP + c0;
-#pragma unroll
-    for (int i = 0; i < REM; ++i) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) pw[r * LDP + 16 * i] = accr[i][r];
-    }
-  }
-  STAMP(2);
-  f32x4 acc[TPW > 0 ? TPW : 1];
-  if constexpr (TPW > 0) {
-#pragma unroll
-    for (int i = 0; i < TPW; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 am[D];
-#pragma unroll
-    for (int g = 0; g < D; ++g) am[g] = *(const f32x4*)(xq + 16 * g);
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-      const int sl = g % D;
-#pragma unroll
-      for (int m = 0; m < 4; ++m) {
-#pragma unroll
-        for (int i = 0; i < TPW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(am[sl][m], p.bm[sl][i][m], acc[i], 0, 0, 0);
-      }
-      if (g + D < NG) {
-#pragma unroll
-        for (int i = 0; i < TPW; ++i) p.bm[sl][i] = *(const f32x4*)(p.wl + ((g + D) * NT + i) * 256);
-        am[sl] = *(const f32x4*)(xq + 16 * (g + D));
-      }
-      // keep the refill D groups ahead of its use: the scheduler would otherwise sink these loads next
-      // to their consumers to save registers, and the wave would wait out a full L2 round trip per group
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-  STAMP(3);
-  next();
-  __builtin_amdgcn_sched_barrier(0);   // the next layer's requests stay ahead of this layer's epilogue
-  if constexpr (TPW > 0) {
-#pragma unroll
-    for (int i = 0; i < TPW; ++i) {
-      const int col = 16 * (wave * TPW + i) + c0;
-      f32x4 v;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = f(r0 + r, col, acc[i][r], hv[i][r]);
-      if (gdst) *(f32x4*)(gdst + col * 16 + r0) = v;
-    }
+  if constexpr (Q::NHEAVY == 0) {
+    dense_tiles<NT, NG, Q::TMAX>(p, xq, r0, c0, pre, f, gdst, next);
+  } else {
+    if (p.w < Q::NHEAVY) dense_tiles<NT, NG, Q::TMAX>(p, xq, r0, c0, pre, f, gdst, next);
+    else if constexpr (Q::TMIN > 0) dense_tiles<NT, NG, Q::TMIN>(p, xq, r0, c0, pre, f, gdst, next);
+    else next();
   }
   STAMP(4);
   lds_barrier();
   STAMP(5);
-  if constexpr (REM > 0) {
-    const int row = threadIdx.x >> 4, col = threadIdx.x & 15;
-    constexpr int WS = ROWS * LDP;
-#pragma unroll
-    for (int i = 0; i < REM; ++i) {
-      const float* q = part + row * LDP + 16 * i + col;
-      const int cc = 16 * (4 * TPW + i) + col;
-      const float v = f(row, cc, ((q[0] + q[WS]) + q[2 * WS]) + q[3 * WS], hr[i]);
-      if (gdst) gdst[cc * 16 + row] = v;
-    }
-    STAMP(6);
-    lds_barrier();
-    STAMP(7);
-  }
 }
 
 // LDS tiles of one network for one 16-row tile
@@ -416,9 +378,13 @@ __device__ __forceinline__ void net_backward(const float* __restrict__ wb, const
 
 // fill the input tile: up to three column blocks, then the constant-1 column, then zeros; rows at or
 // beyond n_rows are zero.  Optionally mirrors the tile to the global x0 work array.
-struct MatIn { const float* p; int ld; int w; int local; };   // local: an LDS tile indexed by tile row
+// local: an LDS tile indexed by tile row; idx (global blocks only, optional): row gr comes from row
+// idx[gr] of the matrix, which is how a minibatch is read straight out of the replay ring
+struct MatIn { const float* p; int ld; int w; int local; const long long* idx; };
 __device__ __forceinline__ float matin_at(const MatIn& b, int gr, int r, int c) {
-  return b.local ? b.p[r * b.ld + c] : b.p[(size_t)gr * b.ld + c];
+  if (b.local) return b.p[r * b.ld + c];
+  const size_t row = b.idx ? (size_t)b.idx[gr] : (size_t)gr;
+  return b.p[row * b.ld + c];
 }
 __device__ __forceinline__ void load_x0(float* x0, int row0, int n_rows, MatIn b0, MatIn b1, MatIn b2,
                                         float* x0_global) {

@@ -157,38 +157,43 @@ class StepEngine:
         return 1.0 / float(n_rows * self.exchange.world)
 
     # ---- argument records of the four row passes ---------------------------------------------------
-    def _critic_args(self, C: CriticState, A: ActorState, s, a, r, s_):
-        n = s.shape[0]
+    @staticmethod
+    def _rows(s, idx) -> int:
+        return s.shape[0] if idx is None else idx.numel()
+
+    def _critic_args(self, C: CriticState, A: ActorState, s, a, r, s_, idx=None):
+        n = self._rows(s, idx)
         R = rows16(n)
         wc = self.workspace("c", C.e, R)
         wa = self.workspace("ca", A.e, R) if C.trains_actor else None
         lp = self.loss_parts("c", R // 16)
         args = _lib.CriticStep(self.s_dim, self.a_dim, n, C.e.net(True), C.t.net(), A.t.net(),
                                A.e.net(True) if C.trains_actor else NULL_NET, mat(s), mat(a), mat(r), mat(s_),
-                               C.gamma, self._inv_gb(n), wc.acts(), wa.acts() if wa is not None else NULL_ACTS, lp.data_ptr())
+                               C.gamma, self._inv_gb(n), wc.acts(), wa.acts() if wa is not None else NULL_ACTS, lp.data_ptr(),
+                               ptr(idx))
         return args, wc, wa, lp
 
-    def _actor_args(self, A: ActorState, C: CriticState, s):
-        n = s.shape[0]
+    def _actor_args(self, A: ActorState, C: CriticState, s, idx=None):
+        n = self._rows(s, idx)
         wa = self.workspace("a", A.e, rows16(n))
-        return _lib.ActorStep(self.s_dim, self.a_dim, n, A.e.net(True), C.e.net(True), mat(s), wa.acts()), wa
+        return _lib.ActorStep(self.s_dim, self.a_dim, n, A.e.net(True), C.e.net(True), mat(s), wa.acts(), ptr(idx)), wa
 
-    def _disc_args(self, D: AdamState, g_data, s_, s, a, smooth):
-        n = s.shape[0]
+    def _disc_args(self, D: AdamState, g_data, s_, s, a, smooth, idx=None):
+        n = self._rows(s, idx)
         R = rows16(n)
         wd = self.workspace("d", D.net, 2 * R)
         lp = self.loss_parts("d", R // 16)
         args = _lib.DiscStep(self.s_dim, self.a_dim, n, D.net.net(True), mat(s), mat(g_data), mat(a), mat(s_),
-                             1.0 - smooth, self._inv_gb(n), wd.acts(), lp.data_ptr())
+                             1.0 - smooth, self._inv_gb(n), wd.acts(), lp.data_ptr(), ptr(idx))
         return args, wd, lp
 
-    def _gen_args(self, G: AdamState, D: AdamState, s, a):
-        n = s.shape[0]
+    def _gen_args(self, G: AdamState, D: AdamState, s, a, idx=None):
+        n = self._rows(s, idx)
         R = rows16(n)
         wg = self.workspace("g", G.net, R)
         lp = self.loss_parts("g", R // 16)
         args = _lib.GenStep(self.s_dim, self.a_dim, n, G.net.net(True), D.net.net(True), mat(s), mat(a),
-                            self._inv_gb(n), wg.acts(), lp.data_ptr())
+                            self._inv_gb(n), wg.acts(), lp.data_ptr(), ptr(idx))
         return args, wg, lp
 
     # ---- job records ------------------------------------------------------------------------------
@@ -273,33 +278,53 @@ class StepEngine:
         return wg
 
     # ---- (5)+(6) post-update losses -------------------------------------------------------------
-    def gan_eval(self, G: AdamState, D: AdamState, g_data, s_, s, a, smooth: float = 0.0):
+    def ticket(self) -> torch.Tensor:
+        """The end-of-launch ticket (one device int32, zero between launches) shared by this engine's calls."""
+        return self._get(("ticket",), lambda: torch.zeros(1, dtype=torch.int32, device=device()))
+
+    def eval_args(self, G: AdamState, D: AdamState, g_data, s_, s, a, smooth: float = 0.0, idx=None) -> _lib.Eval:
+        n = self._rows(s, idx)
+        lp = self.loss_parts("e", 2 * (rows16(n) // 16))
+        out = self.losses[self.LOSS_D_EVAL:self.LOSS_D_EVAL + 2]
+        return _lib.Eval(self.s_dim, self.a_dim, n, G.net.net(), D.net.net(), mat(s), mat(g_data), mat(a), mat(s_),
+                         1.0 - smooth, self._inv_gb(n), lp.data_ptr(), out.data_ptr(), ptr(idx), None, None)
+
+    def eval_args_after_update(self, G: AdamState, D: AdamState, n: int, smooth: float = 0.0) -> _lib.Eval:
+        """Evaluation of the minibatch the last `update` of `n` rows ran on, read from the input tiles
+        its D and G steps left in the work arrays (no gather, the replay ring is not touched)."""
+        R = rows16(n)
+        lp = self.loss_parts("e", 2 * (R // 16))
+        out = self.losses[self.LOSS_D_EVAL:self.LOSS_D_EVAL + 2]
+        wd, wg = self.workspace("d", D.net, 2 * R), self.workspace("g", G.net, R)
+        none = mat(None)
+        return _lib.Eval(self.s_dim, self.a_dim, n, G.net.net(), D.net.net(), none, none, none, none,
+                         1.0 - smooth, self._inv_gb(n), lp.data_ptr(), out.data_ptr(), None,
+                         wd.x0.data_ptr(), wg.x0.data_ptr())
+
+    def gan_eval(self, G: AdamState, D: AdamState, g_data, s_, s, a, smooth: float = 0.0, idx=None):
         """D_loss and G_loss of this rank's shard, divided by the global batch (summing over ranks gives
         the global means); returns the device view [2] of self.losses that receives them."""
-        n = s.shape[0]
-        nt = rows16(n) // 16
-        lp = self.loss_parts("e", 2 * nt)
-        self._timed("gan_eval_rows", lambda: check(lib.rlgan_gan_eval_rows(
-            self.s_dim, self.a_dim, G.net.net(), D.net.net(), mat(s), mat(g_data), mat(a),
-            mat(s_), 1.0 - smooth, n, lp.data_ptr(), _stream()), "rlgan_gan_eval_rows"))
-        out = self.losses[self.LOSS_D_EVAL:self.LOSS_D_EVAL + 2]
-        sum_parts(lp, nt, 2, self._inv_gb(n), out)
-        return out
+        args = self.eval_args(G, D, g_data, s_, s, a, smooth, idx)
+        self._timed("gan_eval_rows", lambda: check(lib.rlgan_gan_eval_rows(args, self.ticket().data_ptr(), _stream()),
+                                                   "rlgan_gan_eval_rows"))
+        return self.losses[self.LOSS_D_EVAL:self.LOSS_D_EVAL + 2]
 
     # ---- fused update: two phases, one launch per stage, one exchange per phase ---------------------
     def update(self, A: ActorState, C: CriticState, G: AdamState, D: AdamState, batch: torch.Tensor,
-               smooth: float = 0.0, with_eval: bool = True, use_curious_reward: bool = True):
+               smooth: float = 0.0, with_eval: bool = True, use_curious_reward: bool = True,
+               idx: Optional[torch.Tensor] = None):
         """One reference update on a [B, 3S+A+2] fp32 batch in the 6-field replay layout
-        (Curious_GAN.py:162,199-213).  Losses land in self.losses (device)."""
+        (Curious_GAN.py:162,199-213).  With `idx` (int64 [B], device) `batch` is the replay ring itself and
+        minibatch row i is ring row idx[i].  Losses land in self.losses (device)."""
         S, Ad = self.s_dim, self.a_dim
-        n = batch.shape[0]
+        n = self._rows(batch, idx)
         b_s, b_s_, b_g = batch[:, :S], batch[:, S:2 * S], batch[:, 2 * S:3 * S]
         b_a = batch[:, 3 * S:3 * S + Ad]
         b_r = batch[:, 3 * S + Ad + (1 if use_curious_reward else 0)]
         nc, na, nd, ng = C.e.n_params, A.e.n_params, D.net.n_params, G.net.n_params
         # phase 1: critic step and discriminator step, tile by tile in one launch
-        cargs, wc, wa, lpc = self._critic_args(C, A, b_s, b_a, b_r, b_s_)
-        dargs, wd, lpd = self._disc_args(D, b_g, b_s_, b_s, b_a, smooth)
+        cargs, wc, wa, lpc = self._critic_args(C, A, b_s, b_a, b_r, b_s_, idx)
+        dargs, wd, lpd = self._disc_args(D, b_g, b_s_, b_s, b_a, smooth, idx)
         b1 = self.bucket("p1", nc + na + nd)
         wc.grad = b1[:nc]
         if wa is not None:
@@ -312,8 +337,8 @@ class StepEngine:
         self.exchange.all_reduce_sum(b1)
         launch_apply(self._critic_apply_jobs(C, A, wc, wa) + [adam_job(D.net, wd.grad, D.m, D.v, D.step, D.lr)])
         # phase 2: actor step and generator step (both read the nets phase 1 just updated)
-        aargs, wa2 = self._actor_args(A, C, b_s)
-        gargs, wg, lpg = self._gen_args(G, D, b_s, b_a)
+        aargs, wa2 = self._actor_args(A, C, b_s, idx)
+        gargs, wg, lpg = self._gen_args(G, D, b_s, b_a, idx)
         b2 = self.bucket("p2", na + ng)
         wa2.grad = b2[:na]
         wg.grad = b2[na:]
@@ -324,7 +349,7 @@ class StepEngine:
         self.exchange.all_reduce_sum(b2)
         launch_apply([self._actor_apply_job(A, wa2), adam_job(G.net, wg.grad, G.m, G.v, G.step, G.lr)])
         if with_eval:
-            self.gan_eval(G, D, b_g, b_s_, b_s, b_a, smooth)
+            self.gan_eval(G, D, b_g, b_s_, b_s, b_a, smooth, idx)
 
     def update_ddpg(self, A: ActorState, C: CriticState, batch: torch.Tensor):
         """`train_DDPG`'s update (Curious_GAN.py:271-281): extrinsic reward column, no G/D."""

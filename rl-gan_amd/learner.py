@@ -76,12 +76,10 @@ class CuriousLearner:
         self.ep_t = torch.zeros(cfg.n_env, dtype=torch.int32, device=dev)
         self.n_resets = torch.zeros(1, dtype=torch.int32, device=dev)
         self.memory = DeviceMemory(cfg.memory_capacity, 3 * S + A + 2, rng=MT19937Device(cfg.seed + 7919 * rank))
-        self.var = torch.full((1,), cfg.var_init, dtype=torch.float32, device=dev)
-        self.noise = torch.zeros((cfg.n_env, A), dtype=torch.float32, device=dev)
+        self.var = torch.full((1,), cfg.var_init, dtype=torch.float64, device=dev)
         self.u = torch.zeros((cfg.n_env, 2), dtype=torch.float64, device=dev)
         self.idx = torch.zeros(cfg.batch_size, dtype=torch.int64, device=dev)
-        self.batch = torch.zeros((cfg.batch_size, 3 * S + A + 2), dtype=torch.float32, device=dev)
-        self.philox_seed = (cfg.seed << 20) ^ (rank + 1)
+        self.philox_seed = ((cfg.seed << 20) ^ (rank + 1)) or 1
         self.ctr = torch.zeros(2, dtype=torch.int64, device=dev)   # device counters: replay pointer, vector steps
         self.t = 0           # vector steps taken (host mirror of ctr[1])
         self.updates = 0
@@ -95,30 +93,35 @@ class CuriousLearner:
         self.env.reset(self.u)
         self.ep_t.zero_()
 
-    def _rollout_body(self, noise: Optional[torch.Tensor] = None) -> None:
-        """Acting step + episode cut.  Every per-step scalar (replay position, random-stream offset)
-        is read from the device counters `self.ctr`, so the same launches can be replayed as a graph."""
-        cfg = self.cfg
-        n = cfg.n_env
-        step = self.ctr[1:].data_ptr()
-        if noise is None:
-            check(lib.rlgan_philox_normal(self.noise.data_ptr(), n, self.philox_seed, 0, 0, step, n, _stream()),
-                  "rlgan_philox_normal")
-            noise = self.noise
+    def _act_args(self, noise: Optional[torch.Tensor] = None) -> _lib.Act:
+        """The acting step of every environment with its bookkeeping: noise and goal draws (Philox, keyed
+        by the device step counter), replay store, episode cut, counters, noise-scale decay.  Every
+        per-step scalar is read from device memory, so the same launch can be replayed in a graph."""
+        cfg, m = self.cfg, self.memory
+        return _lib.Act(cfg.s_dim, cfg.a_dim, cfg.n_env, self.actor.e.net(), self.gen.net.net(), self.disc.net.net(),
+                        self.env.handle(), self.env.state32.data_ptr(), noise.data_ptr() if noise is not None else None,
+                        self.var.data_ptr(), cfg.ita, m._data.data_ptr(), m.capacity, m.dims, m.ld, 0, 0,
+                        self.ctr.data_ptr(), self.env.reward.data_ptr(), self.env.done.data_ptr(), self.philox_seed,
+                        self.ep_t.data_ptr(), cfg.max_ep_steps, 1 if cfg.mode == 'hard' else 0, None,
+                        self.n_resets.data_ptr(), cfg.var_decay, cfg.var_min)
+
+    def _sample_args(self) -> _lib.Sample:
         m = self.memory
-        check(lib.rlgan_act_rows(cfg.s_dim, cfg.a_dim, self.actor.e.net(), self.gen.net.net(), self.disc.net.net(),
-                                 self.env.handle(), n, self.env.state32.data_ptr(), noise.data_ptr(), self.var.data_ptr(),
-                                 cfg.ita, m._data.data_ptr(), m.capacity, m.dims, m.ld, 0, self.ctr.data_ptr(),
-                                 self.env.reward.data_ptr(), self.env.done.data_ptr(), _stream()), "rlgan_act_rows")
-        check(lib.rlgan_philox_uniform(self.u.data_ptr(), n, self.philox_seed, 1, n, step, n, _stream()), "rlgan_philox_uniform")
-        check(lib.rlgan_env_autoreset(self.env.handle(), n, 1 if cfg.mode == 'hard' else 0, self.env.done.data_ptr(),
-                                      self.ep_t.data_ptr(), cfg.max_ep_steps, self.u.data_ptr(),
-                                      self.env.state32.data_ptr(), self.n_resets.data_ptr(), self.ctr.data_ptr(), _stream()),
-              "rlgan_env_autoreset")
+        return _lib.Sample(m.rng.state.data_ptr(), m.capacity, self.cfg.batch_size, self.idx.data_ptr())
+
+    def _ring_fields(self):
+        S, A = self.cfg.s_dim, self.cfg.a_dim
+        d = self.memory._data
+        return d[:, :S], d[:, S:2 * S], d[:, 2 * S:3 * S], d[:, 3 * S:3 * S + A]      # s, s_, g, a
 
     def rollout_step(self, noise: Optional[torch.Tensor] = None) -> None:
-        """One acting step of every environment (Curious_GAN.py:190-195) and the episode cut."""
-        self._rollout_body(noise)
+        """One acting step of every environment (Curious_GAN.py:190-198) and the episode cut; once the
+        ring is full the same launch draws the indices of the next minibatch (Curious_GAN.py:199)."""
+        full = self.memory.pointer + self.cfg.n_env > self.memory.capacity
+        act = self._act_args(noise)
+        sample = self._sample_args() if full else None
+        check(lib.rlgan_rollout_eval_rows(act, None, sample, self.engine.ticket().data_ptr(), _stream()),
+              "rlgan_rollout_eval_rows")
         self.memory.pointer += self.cfg.n_env      # host mirror of ctr[0]
         self.t += 1                                # host mirror of ctr[1]
 
@@ -127,20 +130,30 @@ class CuriousLearner:
         return self.memory.pointer > self.memory.capacity          # Curious_GAN.py:197
 
     def _update_body(self) -> None:
-        cfg = self.cfg
-        self.var.mul_(cfg.var_decay).clamp_(min=cfg.var_min)        # Curious_GAN.py:198
-        self.memory.sample_indices(cfg.batch_size, self.idx)        # Curious_GAN.py:199
-        self.memory.gather(self.idx, self.batch)
-        self.engine.update(self.actor, self.critic, self.gen, self.disc, self.batch, cfg.smooth)
+        """critic/D then actor/G steps on the minibatch ring[idx] (Curious_GAN.py:200-211)."""
+        self.engine.update(self.actor, self.critic, self.gen, self.disc, self.memory._data, self.cfg.smooth,
+                           with_eval=False, idx=self.idx)
+
+    def _tail_body(self) -> None:
+        """Everything between two updates that only reads the networks, as one launch: D_loss / G_loss of
+        the update just done (Curious_GAN.py:212-213), the next acting step and the next index draw."""
+        ev = self.engine.eval_args_after_update(self.gen, self.disc, self.cfg.batch_size, self.cfg.smooth)
+        act, sample, ticket = self._act_args(), self._sample_args(), self.engine.ticket().data_ptr()
+        self.engine._timed("rollout_eval_rows", lambda: check(
+            lib.rlgan_rollout_eval_rows(act, ev, sample, ticket, _stream()), "rlgan_rollout_eval_rows"))
 
     def update(self) -> None:
-        """One minibatch update (Curious_GAN.py:198-213).  Losses: self.engine.losses."""
+        """One minibatch update with its two losses (Curious_GAN.py:199-213), without acting.
+        Losses: self.engine.losses."""
         self._update_body()
+        s, s_, g, a = self._ring_fields()
+        self.engine.gan_eval(self.gen, self.disc, g, s_, s, a, self.cfg.smooth, self.idx)
         self.updates += 1
 
     def capture(self) -> None:
-        """Record one full iteration (acting step + update) as a HIP graph; `step()` then replays it.
-        Needs a full replay ring.  Two eager iterations run first so every work array exists."""
+        """Record one full iteration (update, then losses + next acting step) as a HIP graph; `step()`
+        then replays it.  Needs a full replay ring.  Two eager iterations run first so every work
+        array exists."""
         assert self.ready(), "fill() the replay ring before capture()"
         assert self.engine.kernel_events is None
         cur = torch.cuda.current_stream()
@@ -148,27 +161,31 @@ class CuriousLearner:
         s.wait_stream(cur)
         with torch.cuda.stream(s):
             for _ in range(2):
-                self.rollout_step()
-                self.update()
+                self.step()
         cur.wait_stream(s)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            self._rollout_body()
             self._update_body()
+            self._tail_body()
         self._graph = g
 
     def step(self) -> None:
-        """One iteration of the training loop: act, store, learn when the ring is full."""
+        """One iteration of the training loop.  While the ring fills: an acting step.  Afterwards: the
+        update on the minibatch drawn after the previous acting step, then (one launch) its losses, the
+        next acting step and the next draw -- the reference's act/store/sample/learn order, cut between
+        `sample` and `learn` instead of before `act`."""
+        if not self.ready():
+            self.rollout_step()
+            return
         if self._graph is not None:
             self._graph.replay()
-            self.memory.pointer += self.cfg.n_env
-            self.t += 1
-            self.updates += 1
-            return
-        self.rollout_step()
-        if self.ready():
-            self.update()
+        else:
+            self._update_body()
+            self._tail_body()
+        self.memory.pointer += self.cfg.n_env
+        self.t += 1
+        self.updates += 1
 
     def fill(self) -> None:
         """Roll out until the replay ring is full (no learning, like the reference's first

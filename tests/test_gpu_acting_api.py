@@ -23,7 +23,7 @@ def test_fused_acting_step_matches_oracle_sequence():
     s = oenv.reset(np.ones(n, bool), u)
     env.reset(torch.from_numpy(u).cuda())
     mem = R.DeviceMemory(cap, 25, rng=R.MT19937Device(1))
-    var = torch.tensor([2.0], dtype=torch.float32, device="cuda")
+    var = torch.tensor([2.0], dtype=torch.float64, device="cuda")
     rows_ref = []
     for t in range(5):
         z = rng.randn(n, 2).astype(np.float32)
@@ -33,10 +33,11 @@ def test_fused_acting_step_matches_oracle_sequence():
         s_, r, done = oenv.step(a)
         cr = p.o.intrinsic_reward(r, s.astype(np.float32), a.astype(np.float32), g.astype(np.float32))
         rows_ref.append(np.hstack([s, s_, g, a, r[:, None], cr]))
-        _lib.check(_lib.lib.rlgan_act_rows(7, 2, p.A.e.net(), p.G.net.net(), p.D.net.net(), env.handle(), n,
-                                           env.state32.data_ptr(), torch.from_numpy(z).cuda().data_ptr(), var.data_ptr(), 0.01,
-                                           mem._data.data_ptr(), cap, 25, mem.ld, mem.pointer, None,
-                                           env.reward.data_ptr(), env.done.data_ptr(), _stream()))
+        zt = torch.from_numpy(z).cuda()
+        act = _lib.Act(7, 2, n, p.A.e.net(), p.G.net.net(), p.D.net.net(), env.handle(), env.state32.data_ptr(),
+                       zt.data_ptr(), var.data_ptr(), 0.01, mem._data.data_ptr(), cap, 25, mem.ld, mem.pointer, t,
+                       None, env.reward.data_ptr(), env.done.data_ptr(), 0, None, 0, 1, None, None, 0.0, 0.0)
+        _lib.check(_lib.lib.rlgan_act_rows(act, None, _stream()))
         mem.pointer += n
         np.testing.assert_array_equal(env.reward.cpu().numpy(), r)
         np.testing.assert_allclose(env.state32.cpu().numpy(), s_.astype(np.float32), rtol=0, atol=2e-6)
@@ -148,12 +149,14 @@ def test_vectorised_learner_runs_and_is_deterministic():
         L = R.CuriousLearner(cfg)
         L.fill()
         assert L.memory.pointer == 1280 and not np.isnan(L.memory.data).any()
+        assert L.ctr.tolist() == [1280, 5]
         for _ in range(3):
             L.step()
         torch.cuda.synchronize()
         runs.append((L.losses(), L.actor.e.get_flat(), L.disc.net.get_flat(), L.memory.data.copy(), float(L.var.item())))
         assert L.updates == 3 and all(np.isfinite(v) for v in L.losses().values())
-        assert abs(runs[-1][4] - 2.0 * 0.9999 ** 3) < 1e-6
+        # one decay per acting step taken with a full ring: the last step of fill() and the three after it
+        assert abs(runs[-1][4] - 2.0 * 0.9999 ** 4) < 1e-12
     assert runs[0][0] == runs[1][0]
     np.testing.assert_array_equal(runs[0][1], runs[1][1])
     np.testing.assert_array_equal(runs[0][2], runs[1][2])

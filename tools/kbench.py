@@ -37,7 +37,7 @@ def main():
     L.fill()
     L.update()
     e, A, C, G, D = L.engine, L.actor, L.critic, L.gen, L.disc
-    bt = L.batch
+    bt = L.memory.gather(L.idx)
     s, s_, g, a, r = bt[:, :7], bt[:, 7:14], bt[:, 14:21], bt[:, 21:23], bt[:, 24]
     rows = {}
     rows["critic_step_rows"] = timeit(lambda: e.critic_rows(C, A, s, a, r, s_))
@@ -64,9 +64,9 @@ def main():
         us = timeit(fn)
         tf = 2.0 * MACS_PER_ROW[name] * B / (us * 1e-6) / 1e12
         print(f"{name:22s} {us:8.1f} us  {tf:6.1f} TFLOP/s  {100 * tf / PEAK_FP32_TFLOPS:5.1f}% of fp32 peak")
-    print(f"{'act step (rollout)':22s} {timeit(L.rollout_step):8.1f} us  (philox + act + autoreset)")
-    print(f"{'sample + gather':22s} {timeit(lambda: L.memory.gather(L.memory.sample_indices(B, L.idx), L.batch)):8.1f} us")
-    print(f"{'full update (eager)':22s} {timeit(L.update):8.1f} us")
+    print(f"{'act step + draw':22s} {timeit(L.rollout_step):8.1f} us  (one launch: noise, act, env, store, cut, indices)")
+    print(f"{'losses + act + draw':22s} {timeit(L._tail_body):8.1f} us  (one launch)")
+    print(f"{'update (eager)':22s} {timeit(L._update_body):8.1f} us")
     L.capture()
     print(f"{'full step (graph)':22s} {timeit(L.step):8.1f} us")
 

@@ -17,7 +17,7 @@ L = R.CuriousLearner(R.LearnerConfig(n_env=B, batch_size=B, memory_capacity=max(
 L.fill()
 L.update()
 e, A, C, G, D = L.engine, L.actor, L.critic, L.gen, L.disc
-bt = L.batch
+bt = L.memory.gather(L.idx)
 s, s_, g, a, r = bt[:, :7], bt[:, 7:14], bt[:, 14:21], bt[:, 21:23], bt[:, 24]
 fn = {"critic": lambda: e.critic_rows(C, A, s, a, r, s_), "actor": lambda: e.actor_rows(A, C, s),
       "disc": lambda: e.disc_rows(D, g, s_, s, a), "gen": lambda: e.gen_rows(G, D, s, a),
