@@ -126,7 +126,7 @@ constexpr int T3_FLOATS = ROWS * LD_3W;              // h3 tile (16 or 64 column
 constexpr int X0_FLOATS = ROWS * LD_X0;
 constexpr int O_FLOATS = ROWS * LD_O;
 #ifndef RLGAN_GD
-#define RLGAN_GD 4
+#define RLGAN_GD 2
 #endif
 constexpr int GD = RLGAN_GD;                         // k-groups of operands kept in flight per wave
 
