@@ -105,7 +105,10 @@ int rlgan_mlp_forward(int kind, int s_dim, int a_dim, rlgan_net_t net,
  * `row_idx` (device int64[n_rows], may be NULL): when given, minibatch row i of every input matrix of
  * the step is read from row row_idx[i] of that matrix -- the matrices then point into the replay ring
  * and the fancy-index copy of Memory.sample (Curious_GAN.py:169) needs no pass of its own.  Indices
- * must lie inside the ring; they are not checked.                                              */
+ * must lie inside the ring; they are not checked.
+ * `counter` (device int32, may be NULL) is incremented once by the launch: the t_replace_counter of
+ * Actor/Critic (DDPG.py:64,101,178) or the step count Adam's bias correction uses.  Doing it here
+ * lets the optimizer launch that follows read the new value.                                   */
 
 /* Critic.learn DDPG.py:141-148,174-175: y = r + gamma*q'(s_, a'(s_)); L = mean (y-q(s,a))^2.
  * When `actor_eval.wf` is non-NULL the gradient is continued into the actor eval net with TanhGrad
@@ -118,6 +121,7 @@ typedef struct {
   rlgan_acts_t acts_critic, acts_actor;
   float* loss_parts;
   const int64_t* row_idx;
+  int32_t* counter;
 } rlgan_critic_step_t;
 int rlgan_critic_step_rows(const rlgan_critic_step_t* step, void* stream);
 
@@ -128,6 +132,7 @@ typedef struct {
   rlgan_mat_t s;
   rlgan_acts_t acts_actor;
   const int64_t* row_idx;
+  int32_t* counter;
 } rlgan_actor_step_t;
 int rlgan_actor_step_rows(const rlgan_actor_step_t* step, void* stream);
 
@@ -141,6 +146,7 @@ typedef struct {
   rlgan_acts_t acts_disc;
   float* loss_parts;
   const int64_t* row_idx;
+  int32_t* counter;
 } rlgan_disc_step_t;
 int rlgan_disc_step_rows(const rlgan_disc_step_t* step, void* stream);
 
@@ -153,6 +159,7 @@ typedef struct {
   rlgan_acts_t acts_gen;
   float* loss_parts;
   const int64_t* row_idx;
+  int32_t* counter;
 } rlgan_gen_step_t;
 int rlgan_gen_step_rows(const rlgan_gen_step_t* step, void* stream);
 
@@ -208,7 +215,11 @@ int rlgan_grad_reduce(const rlgan_reduce_job_t* jobs, int n_jobs, void* stream);
  *         rlgan_grad_reduce), eps outside the sqrt.
  * When target_canon is non-NULL the job also updates that target network from the new weights:
  * target <- tau*w + (1-tau)*target when (counter[0]-1) % period == 0 (counter NULL: always); the
- * reference only has the hard copy, tau = 1 (DDPG.py:99-101,176-178). */
+ * reference only has the hard copy, tau = 1 (DDPG.py:99-101,176-178).
+ * When `reduce` is non-NULL the reduction it describes (see rlgan_grad_reduce; its `counter` must be
+ * NULL, its n_params equal) runs in the same launch and feeds the optimizer directly, `grad` is then
+ * ignored and reduce->grad, if non-NULL, receives the gradient: the one-process form, where nothing
+ * has to happen between reduction and optimizer. */
 typedef struct {
   int32_t opt; int32_t n_params;
   float* canon; const float* grad; float* slot0; float* slot1;
@@ -216,6 +227,7 @@ typedef struct {
   const int32_t* step;
   const int32_t* map_f; float* wf; const int32_t* map_b; float* wb;
   float* target_canon; float* target_wf; float tau; const int32_t* counter; int32_t period;
+  const rlgan_reduce_job_t* reduce;   /* host pointer, may be NULL */
 } rlgan_apply_job_t;
 int rlgan_apply(const rlgan_apply_job_t* jobs, int n_jobs, void* stream);
 

@@ -45,25 +45,26 @@ class CriticStep(C.Structure):
                 ("critic_eval", Net), ("critic_target", Net), ("actor_target", Net), ("actor_eval", Net),
                 ("s", Mat), ("a", Mat), ("r", Mat), ("s_next", Mat),
                 ("gamma", C.c_float), ("inv_global_batch", C.c_float),
-                ("acts_critic", Acts), ("acts_actor", Acts), ("loss_parts", _fp), ("row_idx", _fp)]
+                ("acts_critic", Acts), ("acts_actor", Acts), ("loss_parts", _fp), ("row_idx", _fp),
+                ("counter", _fp)]
 
 
 class ActorStep(C.Structure):
     _fields_ = [("s_dim", _i32), ("a_dim", _i32), ("n_rows", _i32), ("actor_eval", Net), ("critic_eval", Net),
-                ("s", Mat), ("acts_actor", Acts), ("row_idx", _fp)]
+                ("s", Mat), ("acts_actor", Acts), ("row_idx", _fp), ("counter", _fp)]
 
 
 class DiscStep(C.Structure):
     _fields_ = [("s_dim", _i32), ("a_dim", _i32), ("n_rows", _i32), ("disc", Net),
                 ("s", Mat), ("g_stored", Mat), ("a", Mat), ("s_next", Mat),
                 ("label_real", C.c_float), ("inv_global_batch", C.c_float), ("acts_disc", Acts), ("loss_parts", _fp),
-                ("row_idx", _fp)]
+                ("row_idx", _fp), ("counter", _fp)]
 
 
 class GenStep(C.Structure):
     _fields_ = [("s_dim", _i32), ("a_dim", _i32), ("n_rows", _i32), ("gen", Net), ("disc", Net),
                 ("s", Mat), ("a", Mat), ("inv_global_batch", C.c_float), ("acts_gen", Acts), ("loss_parts", _fp),
-                ("row_idx", _fp)]
+                ("row_idx", _fp), ("counter", _fp)]
 
 
 class Eval(C.Structure):
@@ -101,7 +102,8 @@ class ApplyJob(C.Structure):
     _fields_ = [("opt", _i32), ("n_params", _i32), ("canon", _fp), ("grad", _fp), ("slot0", _fp), ("slot1", _fp),
                 ("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_float),
                 ("step", _fp), ("map_f", _fp), ("wf", _fp), ("map_b", _fp), ("wb", _fp),
-                ("target_canon", _fp), ("target_wf", _fp), ("tau", C.c_float), ("counter", _fp), ("period", _i32)]
+                ("target_canon", _fp), ("target_wf", _fp), ("tau", C.c_float), ("counter", _fp), ("period", _i32),
+                ("reduce", C.POINTER(ReduceJob))]
 
 
 def _load():

@@ -206,7 +206,7 @@ def rmsprop_job(net: DeviceNet, grad: torch.Tensor, ms: torch.Tensor, lr: float,
     return _lib.ApplyJob(0, net.n_params, net.canon.data_ptr(), grad.data_ptr(), ms.data_ptr(), None,
                          lr, decay, 0.0, eps, None, net.map_f.data_ptr(), net.wf.data_ptr(), ptr(net.map_b), ptr(net.wb),
                          None if target is None else target.canon.data_ptr(),
-                         None if target is None else target.wf.data_ptr(), tau, ptr(counter), period)
+                         None if target is None else target.wf.data_ptr(), tau, ptr(counter), period, None)
 
 
 def adam_job(net: DeviceNet, grad: torch.Tensor, m: torch.Tensor, v: torch.Tensor, step: torch.Tensor, lr: float,
@@ -214,7 +214,7 @@ def adam_job(net: DeviceNet, grad: torch.Tensor, m: torch.Tensor, v: torch.Tenso
     """tf.train.AdamOptimizer step (Curious_GAN.py:45,142)."""
     return _lib.ApplyJob(1, net.n_params, net.canon.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(),
                          lr, beta1, beta2, eps, step.data_ptr(), net.map_f.data_ptr(), net.wf.data_ptr(),
-                         ptr(net.map_b), ptr(net.wb), None, None, 1.0, None, 0)
+                         ptr(net.map_b), ptr(net.wb), None, None, 1.0, None, 0, None)
 
 
 def _arr(cls, jobs):
@@ -229,7 +229,13 @@ def launch_reduce(jobs) -> None:
     check(lib.rlgan_grad_reduce(_arr(_lib.ReduceJob, jobs), len(jobs), _stream()), "rlgan_grad_reduce")
 
 
-def launch_apply(jobs) -> None:
+def launch_apply(jobs, reduces=None) -> None:
+    """Optimizer steps; with `reduces` (one ReduceJob per apply job) the chunk reduction of the weight
+    gradients runs inside the same launch."""
+    if reduces is not None:
+        assert len(reduces) == len(jobs)
+        for j, r in zip(jobs, reduces):
+            j.reduce = C.pointer(r)
     check(lib.rlgan_apply(_arr(_lib.ApplyJob, jobs), len(jobs), _stream()), "rlgan_apply")
 
 

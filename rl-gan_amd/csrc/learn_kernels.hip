@@ -18,10 +18,12 @@ struct CriticArgs {
   int n_rows, train_actor;
   Acts8 acts_c, acts_a;
   float* loss_parts;
+  int32_t* counter;           // optional: += 1 per launch (t_replace_counter, DDPG.py:64,178)
 };
 constexpr int CRITIC_LDS = PART_FLOATS + SET_FLOATS + O_FLOATS + 64;
 
 __device__ __forceinline__ void critic_tile(const CriticArgs& A, float* smem, int tile) {
+  if (tile == 0 && threadIdx.x == 0 && A.counter) A.counter[0] += 1;   // nothing in this launch reads it
   float* part = smem;
   TileSet ts = carve_set(smem + PART_FLOATS);
   float* dsave = smem + PART_FLOATS + SET_FLOATS;   // [16][LD_O]
@@ -109,10 +111,12 @@ struct ActorArgs {
   Mat s;
   int n_rows;
   Acts8 acts_a;
+  int32_t* counter;           // optional: += 1 per launch (t_replace_counter, DDPG.py:64,101)
 };
 constexpr int ACTOR_LDS = PART_FLOATS + 2 * SET_FLOATS;
 
 __device__ __forceinline__ void actor_tile(const ActorArgs& A, float* smem, int tile) {
+  if (tile == 0 && threadIdx.x == 0 && A.counter) A.counter[0] += 1;   // nothing in this launch reads it
   float* part = smem;
   const TileSet sa = carve_set(smem + PART_FLOATS);
   const TileSet sc = carve_set(smem + PART_FLOATS + SET_FLOATS);
@@ -167,10 +171,12 @@ struct DiscArgs {
   int n_rows, rows16;
   Acts8 acts_d;
   float* loss_parts;
+  int32_t* counter;           // optional: += 1 per launch (the optimizer's step count)
 };
 constexpr int DISC_LDS = PART_FLOATS + SET_FLOATS + 64;
 
 __device__ __forceinline__ void disc_tile(const DiscArgs& A, float* smem, int tile) {
+  if (tile == 0 && threadIdx.x == 0 && A.counter) A.counter[0] += 1;   // nothing in this launch reads it
   float* part = smem;
   const TileSet ts = carve_set(smem + PART_FLOATS);
   float* small = smem + PART_FLOATS + SET_FLOATS;
@@ -218,10 +224,12 @@ struct GenArgs {
   int n_rows;
   Acts8 acts_g;
   float* loss_parts;
+  int32_t* counter;           // optional: += 1 per launch (the optimizer's step count)
 };
 constexpr int GEN_LDS = PART_FLOATS + 2 * SET_FLOATS + 64;
 
 __device__ __forceinline__ void gen_tile(const GenArgs& A, float* smem, int tile) {
+  if (tile == 0 && threadIdx.x == 0 && A.counter) A.counter[0] += 1;   // nothing in this launch reads it
   float* part = smem;
   const TileSet sg = carve_set(smem + PART_FLOATS);
   const TileSet sd = carve_set(smem + PART_FLOATS + SET_FLOATS);
@@ -501,6 +509,10 @@ struct ApplyJob {
   double lr, beta1, beta2;             // RMSProp: beta1 = decay
   float eps, tau;
   int opt, n, period, blk0;            // opt: 0 = RMSProp, 1 = Adam
+  // optional reduction over batch chunks in the same launch (gslabs null: the gradient is read from grad)
+  const float* gslabs; const int32_t* map_g; float* grad_out;
+  const float* loss_parts; float* loss_out;
+  int nchunks, gstride, n_parts; float loss_scale;
 };
 struct ApplyArgs { ApplyJob job[MAX_JOBS]; int n_jobs; };
 
@@ -511,9 +523,29 @@ __global__ __launch_bounds__(256) void apply_kernel(const ApplyArgs A) {
   ApplyJob J = A.job[0];
 #pragma unroll
   for (int i = 1; i < MAX_JOBS; ++i) if (ji == i) J = A.job[i];
-  const int p = (blockIdx.x - J.blk0) * 256 + threadIdx.x;
+  const int blk = blockIdx.x - J.blk0;
+  const int p = blk * 256 + threadIdx.x;
+  if (J.gslabs && J.loss_out && blk == 0 && threadIdx.x < 64) {
+    float s = 0.f;
+    for (int i = threadIdx.x; i < J.n_parts; i += 64) s += J.loss_parts[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+    if (threadIdx.x == 0) J.loss_out[0] = s * J.loss_scale;
+  }
   if (p >= J.n) return;
-  const float g = J.grad[p];
+  float g;
+  if (J.gslabs) {
+    const float* src = J.gslabs + J.map_g[p];
+    float v[MAX_CHUNKS];
+#pragma unroll
+    for (int c = 0; c < MAX_CHUNKS; ++c) v[c] = c < J.nchunks ? src[(size_t)c * J.gstride] : 0.f;
+    g = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAX_CHUNKS; ++c) g += v[c];          // chunk order: bitwise reproducible
+    if (J.grad_out) J.grad_out[p] = g;
+  } else {
+    g = J.grad[p];
+  }
   float w;
   if (J.opt == 0) {
     // tf.train.RMSPropOptimizer: ms <- decay*ms + (1-decay)*g^2 ; w <- w - lr*g/sqrt(ms + eps)
@@ -584,7 +616,7 @@ int make_critic_args(CriticArgs& A, const rlgan_critic_step_t* c) {
   A.critic_e = NP(c->critic_eval); A.critic_t = NP(c->critic_target); A.actor_t = NP(c->actor_target); A.actor_e = NP(c->actor_eval);
   A.s = M(c->s, c->row_idx); A.a = M(c->a, c->row_idx); A.r = M(c->r, c->row_idx); A.s_next = M(c->s_next, c->row_idx);
   A.gamma = c->gamma; A.inv_gb = c->inv_global_batch; A.n_rows = c->n_rows;
-  A.acts_c = A8(c->acts_critic); A.acts_a = A8(c->acts_actor); A.loss_parts = c->loss_parts;
+  A.acts_c = A8(c->acts_critic); A.acts_a = A8(c->acts_actor); A.loss_parts = c->loss_parts; A.counter = c->counter;
   return 0;
 }
 int make_actor_args(ActorArgs& A, const rlgan_actor_step_t* c) {
@@ -592,7 +624,7 @@ int make_actor_args(ActorArgs& A, const rlgan_actor_step_t* c) {
   if (!make_geo(NET_CRITIC, c->s_dim, c->a_dim, A.gc) || !make_geo(NET_ACTOR, c->s_dim, c->a_dim, A.ga)) return RLGAN_E_DIMS;
   if (c->n_rows <= 0 || !c->actor_eval.wf || !c->actor_eval.wb || !c->critic_eval.wf || !c->critic_eval.wb || !c->s.p ||
       !acts_ok(c->acts_actor)) return RLGAN_E_ARG;
-  A.actor_e = NP(c->actor_eval); A.critic_e = NP(c->critic_eval); A.s = M(c->s, c->row_idx); A.n_rows = c->n_rows; A.acts_a = A8(c->acts_actor);
+  A.actor_e = NP(c->actor_eval); A.critic_e = NP(c->critic_eval); A.s = M(c->s, c->row_idx); A.n_rows = c->n_rows; A.acts_a = A8(c->acts_actor); A.counter = c->counter;
   return 0;
 }
 int make_disc_args(DiscArgs& A, const rlgan_disc_step_t* c) {
@@ -602,7 +634,7 @@ int make_disc_args(DiscArgs& A, const rlgan_disc_step_t* c) {
       !acts_ok(c->acts_disc)) return RLGAN_E_ARG;
   A.disc = NP(c->disc); A.s = M(c->s, c->row_idx); A.g = M(c->g_stored, c->row_idx); A.a = M(c->a, c->row_idx); A.s_next = M(c->s_next, c->row_idx);
   A.label_real = c->label_real; A.inv_gb = c->inv_global_batch; A.n_rows = c->n_rows; A.rows16 = cdiv(c->n_rows, ROWS) * ROWS;
-  A.acts_d = A8(c->acts_disc); A.loss_parts = c->loss_parts;
+  A.acts_d = A8(c->acts_disc); A.loss_parts = c->loss_parts; A.counter = c->counter;
   return 0;
 }
 int make_gen_args(GenArgs& A, const rlgan_gen_step_t* c) {
@@ -611,7 +643,7 @@ int make_gen_args(GenArgs& A, const rlgan_gen_step_t* c) {
   if (c->n_rows <= 0 || !c->gen.wf || !c->gen.wb || !c->disc.wf || !c->disc.wb || !c->s.p || !c->a.p || !c->loss_parts ||
       !acts_ok(c->acts_gen)) return RLGAN_E_ARG;
   A.gen = NP(c->gen); A.disc = NP(c->disc); A.s = M(c->s, c->row_idx); A.a = M(c->a, c->row_idx); A.inv_gb = c->inv_global_batch; A.n_rows = c->n_rows;
-  A.acts_g = A8(c->acts_gen); A.loss_parts = c->loss_parts;
+  A.acts_g = A8(c->acts_gen); A.loss_parts = c->loss_parts; A.counter = c->counter;
   return 0;
 }
 
@@ -751,7 +783,7 @@ int rlgan_apply(const rlgan_apply_job_t* jobs, int n_jobs, void* stream) {
   int b = 0;
   for (int i = 0; i < n_jobs; ++i) {
     const rlgan_apply_job_t& J = jobs[i];
-    if (!J.canon || !J.grad || !J.slot0 || !J.map_f || !J.wf || J.n_params <= 0 || (J.wb && !J.map_b)) return RLGAN_E_ARG;
+    if (!J.canon || (!J.grad && !J.reduce) || !J.slot0 || !J.map_f || !J.wf || J.n_params <= 0 || (J.wb && !J.map_b)) return RLGAN_E_ARG;
     if (J.opt != 0 && J.opt != 1) return RLGAN_E_ARG;
     if (J.opt == 1 && (!J.slot1 || !J.step)) return RLGAN_E_ARG;
     if (J.target_canon && (!J.target_wf || (J.counter && J.period <= 0))) return RLGAN_E_ARG;
@@ -761,6 +793,15 @@ int rlgan_apply(const rlgan_apply_job_t* jobs, int n_jobs, void* stream) {
     K.target_canon = J.target_canon; K.target_wf = J.target_wf; K.counter = J.counter;
     K.lr = J.lr; K.beta1 = J.beta1; K.beta2 = J.beta2; K.eps = J.eps; K.tau = J.tau;
     K.opt = J.opt; K.n = J.n_params; K.period = J.period; K.blk0 = b;
+    K.gslabs = nullptr; K.map_g = nullptr; K.grad_out = nullptr; K.loss_parts = nullptr; K.loss_out = nullptr;
+    K.nchunks = 0; K.gstride = 0; K.n_parts = 0; K.loss_scale = 0.f;
+    if (const rlgan_reduce_job_t* R = J.reduce) {
+      // a counter cannot be advanced here: other workgroups of this launch read it
+      if (!R->gslabs || !R->map_g || R->n_params != J.n_params || R->n_chunks <= 0 || R->n_chunks > MAX_CHUNKS ||
+          (R->loss_out && !R->loss_parts) || R->counter) return RLGAN_E_ARG;
+      K.gslabs = R->gslabs; K.map_g = R->map_g; K.grad_out = R->grad; K.loss_parts = R->loss_parts; K.loss_out = R->loss_out;
+      K.nchunks = R->n_chunks; K.gstride = R->gpad_floats; K.n_parts = R->n_parts; K.loss_scale = R->loss_scale;
+    }
     b += cdiv(J.n_params, 256);
   }
   hipLaunchKernelGGL(apply_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, A);

@@ -170,13 +170,14 @@ class StepEngine:
         args = _lib.CriticStep(self.s_dim, self.a_dim, n, C.e.net(True), C.t.net(), A.t.net(),
                                A.e.net(True) if C.trains_actor else NULL_NET, mat(s), mat(a), mat(r), mat(s_),
                                C.gamma, self._inv_gb(n), wc.acts(), wa.acts() if wa is not None else NULL_ACTS, lp.data_ptr(),
-                               ptr(idx))
+                               ptr(idx), C.counter.data_ptr())
         return args, wc, wa, lp
 
     def _actor_args(self, A: ActorState, C: CriticState, s, idx=None):
         n = self._rows(s, idx)
         wa = self.workspace("a", A.e, rows16(n))
-        return _lib.ActorStep(self.s_dim, self.a_dim, n, A.e.net(True), C.e.net(True), mat(s), wa.acts(), ptr(idx)), wa
+        return _lib.ActorStep(self.s_dim, self.a_dim, n, A.e.net(True), C.e.net(True), mat(s), wa.acts(), ptr(idx),
+                              A.counter.data_ptr()), wa
 
     def _disc_args(self, D: AdamState, g_data, s_, s, a, smooth, idx=None):
         n = self._rows(s, idx)
@@ -184,7 +185,7 @@ class StepEngine:
         wd = self.workspace("d", D.net, 2 * R)
         lp = self.loss_parts("d", R // 16)
         args = _lib.DiscStep(self.s_dim, self.a_dim, n, D.net.net(True), mat(s), mat(g_data), mat(a), mat(s_),
-                             1.0 - smooth, self._inv_gb(n), wd.acts(), lp.data_ptr(), ptr(idx))
+                             1.0 - smooth, self._inv_gb(n), wd.acts(), lp.data_ptr(), ptr(idx), D.step.data_ptr())
         return args, wd, lp
 
     def _gen_args(self, G: AdamState, D: AdamState, s, a, idx=None):
@@ -193,13 +194,13 @@ class StepEngine:
         wg = self.workspace("g", G.net, R)
         lp = self.loss_parts("g", R // 16)
         args = _lib.GenStep(self.s_dim, self.a_dim, n, G.net.net(True), D.net.net(True), mat(s), mat(a),
-                            self._inv_gb(n), wg.acts(), lp.data_ptr(), ptr(idx))
+                            self._inv_gb(n), wg.acts(), lp.data_ptr(), ptr(idx), G.step.data_ptr())
         return args, wg, lp
 
     # ---- job records ------------------------------------------------------------------------------
     def _critic_jobs(self, C, A, wc, wa, lp, n):
         wj = [wgrad_job(C.e, wc)]
-        rj = [reduce_job(C.e, wc, lp, lp.numel(), self._inv_gb(n), self.losses[self.LOSS_CRITIC:], C.counter)]
+        rj = [reduce_job(C.e, wc, lp, lp.numel(), self._inv_gb(n), self.losses[self.LOSS_CRITIC:])]
         if wa is not None:
             wj.append(wgrad_job(A.e, wa))
             rj.append(reduce_job(A.e, wa))
@@ -244,7 +245,7 @@ class StepEngine:
     def actor_step(self, A, C, s):
         wa = self.actor_rows(A, C, s)
         launch_wgrads([wgrad_job(A.e, wa)], self.s_dim, self.a_dim)
-        launch_reduce([reduce_job(A.e, wa, counter=A.counter)])
+        launch_reduce([reduce_job(A.e, wa)])
         self.exchange.all_reduce_sum(wa.grad)
         launch_apply([self._actor_apply_job(A, wa)])
         return wa
@@ -258,7 +259,7 @@ class StepEngine:
     def disc_step(self, D, g_data, s_, s, a, smooth: float = 0.0):
         wd, lp = self.disc_rows(D, g_data, s_, s, a, smooth)
         launch_wgrads([wgrad_job(D.net, wd)], self.s_dim, self.a_dim)
-        launch_reduce([reduce_job(D.net, wd, lp, lp.numel(), self._inv_gb(s.shape[0]), self.losses[self.LOSS_D_STEP:], D.step)])
+        launch_reduce([reduce_job(D.net, wd, lp, lp.numel(), self._inv_gb(s.shape[0]), self.losses[self.LOSS_D_STEP:])])
         self.exchange.all_reduce_sum(wd.grad)
         launch_apply([adam_job(D.net, wd.grad, D.m, D.v, D.step, D.lr)])
         return wd
@@ -272,7 +273,7 @@ class StepEngine:
     def gen_step(self, G, D, s, a):
         wg, lp = self.gen_rows(G, D, s, a)
         launch_wgrads([wgrad_job(G.net, wg)], self.s_dim, self.a_dim)
-        launch_reduce([reduce_job(G.net, wg, lp, lp.numel(), self._inv_gb(s.shape[0]), self.losses[self.LOSS_G_STEP:], G.step)])
+        launch_reduce([reduce_job(G.net, wg, lp, lp.numel(), self._inv_gb(s.shape[0]), self.losses[self.LOSS_G_STEP:])])
         self.exchange.all_reduce_sum(wg.grad)
         launch_apply([adam_job(G.net, wg.grad, G.m, G.v, G.step, G.lr)])
         return wg
@@ -333,9 +334,9 @@ class StepEngine:
         self._timed("phase1_rows", lambda: check(lib.rlgan_phase1_rows(cargs, dargs, _stream()), "rlgan_phase1_rows"))
         wj, rj = self._critic_jobs(C, A, wc, wa, lpc, n)
         launch_wgrads(wj + [wgrad_job(D.net, wd)], S, Ad)
-        launch_reduce(rj + [reduce_job(D.net, wd, lpd, lpd.numel(), self._inv_gb(n), self.losses[self.LOSS_D_STEP:], D.step)])
-        self.exchange.all_reduce_sum(b1)
-        launch_apply(self._critic_apply_jobs(C, A, wc, wa) + [adam_job(D.net, wd.grad, D.m, D.v, D.step, D.lr)])
+        self._reduce_exchange_apply(
+            rj + [reduce_job(D.net, wd, lpd, lpd.numel(), self._inv_gb(n), self.losses[self.LOSS_D_STEP:])], b1,
+            self._critic_apply_jobs(C, A, wc, wa) + [adam_job(D.net, wd.grad, D.m, D.v, D.step, D.lr)])
         # phase 2: actor step and generator step (both read the nets phase 1 just updated)
         aargs, wa2 = self._actor_args(A, C, b_s, idx)
         gargs, wg, lpg = self._gen_args(G, D, b_s, b_a, idx)
@@ -344,12 +345,21 @@ class StepEngine:
         wg.grad = b2[na:]
         self._timed("phase2_rows", lambda: check(lib.rlgan_phase2_rows(aargs, gargs, _stream()), "rlgan_phase2_rows"))
         launch_wgrads([wgrad_job(A.e, wa2), wgrad_job(G.net, wg)], S, Ad)
-        launch_reduce([reduce_job(A.e, wa2, counter=A.counter),
-                       reduce_job(G.net, wg, lpg, lpg.numel(), self._inv_gb(n), self.losses[self.LOSS_G_STEP:], G.step)])
-        self.exchange.all_reduce_sum(b2)
-        launch_apply([self._actor_apply_job(A, wa2), adam_job(G.net, wg.grad, G.m, G.v, G.step, G.lr)])
+        self._reduce_exchange_apply(
+            [reduce_job(A.e, wa2), reduce_job(G.net, wg, lpg, lpg.numel(), self._inv_gb(n), self.losses[self.LOSS_G_STEP:])], b2,
+            [self._actor_apply_job(A, wa2), adam_job(G.net, wg.grad, G.m, G.v, G.step, G.lr)])
         if with_eval:
             self.gan_eval(G, D, b_g, b_s_, b_s, b_a, smooth, idx)
+
+    def _reduce_exchange_apply(self, reduce_jobs, bucket: torch.Tensor, apply_jobs) -> None:
+        """Chunk reduction -> sum over ranks -> optimizers.  With one rank nothing happens in between, so
+        the reduction runs inside the optimizer launch."""
+        if self.exchange.enabled:
+            launch_reduce(reduce_jobs)
+            self.exchange.all_reduce_sum(bucket)
+            launch_apply(apply_jobs)
+        else:
+            launch_apply(apply_jobs, reduce_jobs)
 
     def update_ddpg(self, A: ActorState, C: CriticState, batch: torch.Tensor):
         """`train_DDPG`'s update (Curious_GAN.py:271-281): extrinsic reward column, no G/D."""
