@@ -84,6 +84,14 @@ class Act(C.Structure):
                 ("var_decay", C.c_double), ("var_min", C.c_double)]
 
 
+class Conv(C.Structure):
+    _fields_ = [(n, _i32) for n in ("h", "w", "c_in", "c_out", "k", "stride")]
+
+
+class ConvGeom(C.Structure):
+    _fields_ = [(n, _i32) for n in ("h_out", "w_out", "k_len", "n_params", "wfrag_floats", "slab_floats")]
+
+
 class Sample(C.Structure):
     _fields_ = [("mt_state", _fp), ("n_pop", C.c_int64), ("n", _i32), ("out_idx", _fp)]
 
@@ -150,6 +158,12 @@ PROTOTYPES = {
     "rlgan_philox_normal": [_vp, _i, _u64, _u32, _u64, _vp, _i64, _vp],
     "rlgan_philox_uniform": [_vp, _i, _u64, _u32, _u64, _vp, _i64, _vp],
     "rlgan_act_rows": [C.POINTER(Act), _vp, _vp],
+    "rlgan_conv_geometry": [C.POINTER(Conv), C.POINTER(ConvGeom)],
+    "rlgan_conv_build_map": [C.POINTER(Conv), _vp],
+    "rlgan_conv_forward": [C.POINTER(Conv), _vp, _vp, _vp, _i, _i, _vp],
+    "rlgan_elu_backward": [_vp, _vp, _vp, _i64, _vp],
+    "rlgan_conv_backward_input": [C.POINTER(Conv), _vp, _vp, _vp, _i, _vp],
+    "rlgan_conv_backward_weights": [C.POINTER(Conv), _vp, _vp, _vp, _i, _vp, _i, _vp],
 }
 
 for _name, _args in PROTOTYPES.items():

@@ -1,0 +1,117 @@
+"""Pixel feature extractors of the reference on the device: stacks of NHWC 'valid' convolutions with
+ELU (`doom_feature_abstraction` Conv_model.py:15-24 / Conv_DDPG.py:83-86, `universe_feature_abstraction`
+Conv_model.py:36-56 without batch norm).  Forward and weight gradients run as MFMA implicit GEMMs,
+the input gradient as a deterministic gather (librlgan_amd.so, rlgan_conv_*)."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, lib
+from .core import _stream, device
+
+DOOM_HEAD = ((8, 5, 4), (16, 3, 2), (32, 3, 2), (64, 3, 2))     # (filters, kernel, stride), Conv_model.py:15-22
+
+
+def universe_head(n_convs: int = 4):
+    return tuple((32, 3, 2) for _ in range(n_convs))            # Conv_model.py:36-49
+
+
+class ConvLayer:
+    """One conv2d + ELU layer: canonical parameters (HWIO kernel, then bias) and their fragment image."""
+
+    def __init__(self, h: int, w: int, c_in: int, c_out: int, k: int, stride: int, rng: Optional[np.random.RandomState] = None,
+                 bias_init: float = 0.0, kernel: Optional[np.ndarray] = None, bias: Optional[np.ndarray] = None):
+        self.conv = _lib.Conv(h, w, c_in, c_out, k, stride)
+        self.geom = _lib.ConvGeom()
+        check(lib.rlgan_conv_geometry(self.conv, C.byref(self.geom)), "rlgan_conv_geometry")
+        g = self.geom
+        self.h_out, self.w_out, self.c_out, self.c_in, self.k, self.stride = g.h_out, g.w_out, c_out, c_in, k, stride
+        self.n_params = g.n_params
+        if kernel is None:
+            rng = rng or np.random.RandomState()
+            lim = np.sqrt(6.0 / (k * k * c_in + k * k * c_out))                  # tf.layers.conv2d default: glorot uniform
+            kernel = rng.uniform(-lim, lim, (k, k, c_in, c_out))
+            bias = np.full(c_out, bias_init)
+        flat = np.concatenate([np.asarray(kernel, np.float32).ravel(), np.asarray(bias, np.float32).ravel()])
+        assert flat.size == self.n_params
+        dev = device()
+        m = np.empty(self.n_params, np.int32)
+        check(lib.rlgan_conv_build_map(self.conv, m.ctypes.data), "rlgan_conv_build_map")
+        self.map_f = torch.from_numpy(m).to(dev)
+        self.canon = torch.from_numpy(flat).to(dev)
+        self.wfrag = torch.zeros(g.wfrag_floats, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(self.n_params, dtype=torch.float32, device=dev)
+        self.n_slabs = 256
+        self._slabs = None
+        self.pack()
+
+    def pack(self) -> None:
+        check(lib.rlgan_pack_weights(self.canon.data_ptr(), self.n_params, self.map_f.data_ptr(), self.wfrag.data_ptr(),
+                                     None, None, _stream()), "rlgan_pack_weights")
+
+    def kernel_bias(self) -> Tuple[np.ndarray, np.ndarray]:
+        f = self.canon.cpu().numpy()
+        n = self.k * self.k * self.c_in * self.c_out
+        return f[:n].reshape(self.k, self.k, self.c_in, self.c_out), f[n:]
+
+    def forward(self, x: torch.Tensor, act: bool = True) -> torch.Tensor:
+        n = x.shape[0]
+        assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and tuple(x.shape[1:]) == (self.conv.h, self.conv.w, self.c_in)
+        y = torch.empty((n, self.h_out, self.w_out, self.c_out), dtype=torch.float32, device=x.device)
+        check(lib.rlgan_conv_forward(self.conv, x.data_ptr(), self.wfrag.data_ptr(), y.data_ptr(), n, 1 if act else 0, _stream()),
+              "rlgan_conv_forward")
+        return y
+
+    def backward(self, x: torch.Tensor, y: torch.Tensor, dy: torch.Tensor, need_dx: bool = True, act: bool = True):
+        """Gradients of this layer: fills self.grad (kernel then bias), returns dx or None."""
+        n = x.shape[0]
+        dz = dy
+        if act:
+            dz = torch.empty_like(dy)
+            check(lib.rlgan_elu_backward(dy.data_ptr(), y.data_ptr(), dz.data_ptr(), dy.numel(), _stream()), "rlgan_elu_backward")
+        if self._slabs is None:
+            self._slabs = torch.empty(self.n_slabs * self.geom.slab_floats, dtype=torch.float32, device=x.device)
+        check(lib.rlgan_conv_backward_weights(self.conv, x.data_ptr(), dz.data_ptr(), self._slabs.data_ptr(), self.n_slabs,
+                                              self.grad.data_ptr(), n, _stream()), "rlgan_conv_backward_weights")
+        if not need_dx:
+            return None
+        dx = torch.empty_like(x)
+        check(lib.rlgan_conv_backward_input(self.conv, dz.data_ptr(), self.canon.data_ptr(), dx.data_ptr(), n, _stream()),
+              "rlgan_conv_backward_input")
+        return dx
+
+
+class ConvEncoder:
+    """A stack of ConvLayers on [n, h, w, c] frames; output flattened to [n, features] like the
+    reference's `tf.reshape(s, [-1, prod(shape[1:])])` (Conv_model.py:23,51)."""
+
+    def __init__(self, h: int, w: int, c_in: int, layers: Sequence[Tuple[int, int, int]] = DOOM_HEAD,
+                 rng: Optional[np.random.RandomState] = None, bias_init: float = 0.0, params=None):
+        self.layers: List[ConvLayer] = []
+        rng = rng or np.random.RandomState()
+        for i, (f, k, s) in enumerate(layers):
+            kw = {} if params is None else {"kernel": params[i][0], "bias": params[i][1]}
+            L = ConvLayer(h, w, c_in, f, k, s, rng=rng, bias_init=bias_init, **kw)
+            self.layers.append(L)
+            h, w, c_in = L.h_out, L.w_out, f
+        self.features = h * w * c_in
+        self._acts: List[torch.Tensor] = []
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        self._acts = [x]
+        for L in self.layers:
+            x = L.forward(x)
+            self._acts.append(x)
+        return x.reshape(x.shape[0], -1)
+
+    def backward(self, dfeat: torch.Tensor, need_dx: bool = False) -> Optional[torch.Tensor]:
+        """Backpropagates d(loss)/d(features) through the stack; every layer's .grad is filled."""
+        dy = dfeat.reshape(self._acts[-1].shape).contiguous()
+        for i in range(len(self.layers) - 1, -1, -1):
+            dy = self.layers[i].backward(self._acts[i], self._acts[i + 1], dy, need_dx=need_dx or i > 0)
+        return dy
