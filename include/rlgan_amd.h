@@ -337,7 +337,7 @@ int rlgan_rollout_eval_rows(const rlgan_act_t* act, const rlgan_eval_t* eval, co
 /* ---- pixel encoder layers ------------------------------------------------------------------------
  * tf.layers.conv2d(..., padding='valid', activation=tf.nn.elu) on NHWC tensors, the building block of
  * the reference's feature extractors (Conv_model.py:15-24,36-56; Conv_DDPG.py:83-86): square kernel
- * k x k, stride `stride`, c_in a multiple of 4, c_out <= 64.
+ * k x k, stride `stride`, c_in and c_out multiples of 4, c_out <= 64.
  * Parameters in canonical order: the HWIO kernel [k, k, c_in, c_out] row-major (TensorFlow's layout),
  * then bias[c_out]: n_params = (k*k*c_in + 1) * c_out.  On the device the layer is kept like a dense
  * one: `canon` plus a fragment image `wfrag` of [W ; b] (wfrag_floats floats, zero-filled once) that

@@ -46,7 +46,7 @@ class ConvLayer:
         self.canon = torch.from_numpy(flat).to(dev)
         self.wfrag = torch.zeros(g.wfrag_floats, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(self.n_params, dtype=torch.float32, device=dev)
-        self.n_slabs = 256
+        self.n_slabs = 1024      # partial weight-gradient images (one per workgroup of the reduction over pixels)
         self._slabs = None
         self.pack()
 

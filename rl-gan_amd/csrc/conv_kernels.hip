@@ -23,7 +23,7 @@ struct ConvG {
 
 inline bool make_conv(const rlgan_conv_t* c, ConvG& g) {
   if (!c || c->h <= 0 || c->w <= 0 || c->c_in <= 0 || c->c_out <= 0 || c->k <= 0 || c->stride <= 0) return false;
-  if (c->c_in % 4 != 0 || c->c_out > 64 || c->k > c->h || c->k > c->w) return false;   // 16-byte patch segments, <= 4 column tiles
+  if (c->c_in % 4 != 0 || c->c_out % 4 != 0 || c->c_out > 64 || c->k > c->h || c->k > c->w) return false;   // 16-byte segments, <= 4 column tiles
   g.H = c->h; g.W = c->w; g.Cin = c->c_in; g.Cout = c->c_out; g.k = c->k; g.s = c->stride;
   g.Ho = (c->h - c->k) / c->stride + 1; g.Wo = (c->w - c->k) / c->stride + 1;
   g.K = c->k * c->k * c->c_in; g.NG = cdiv(g.K + 1, 16); g.NT = cdiv(c->c_out, 16); g.rowlen = c->k * c->c_in;
@@ -103,17 +103,20 @@ __global__ void elu_bwd_kernel(const float* __restrict__ dy, const float* __rest
 
 // ---------------------------------------------------------------- input gradient
 // dX[b,y,x,c] = sum over (ky,kx) with (y-ky)%s == 0, (x-kx)%s == 0, output pixel inside the map, of
-// dZ[b,oy,ox,:] . W[ky,kx,c,:].  One thread per (input pixel, channel); fixed summation order.
-__global__ void conv_bwd_input_kernel(const ConvG g, const float* __restrict__ dz, const float* __restrict__ w /*[K][Cout]*/,
-                                      float* __restrict__ dx, size_t total) {
+// dZ[b,oy,ox,:] . W[ky,kx,c,:].  One thread per (input pixel, four channels), 16-byte loads over the
+// output channels; fixed summation order, no atomics.
+__global__ __launch_bounds__(256) void conv_bwd_input_kernel(const ConvG g, const float* __restrict__ dz,
+                                                             const float* __restrict__ w /*[K][Cout]*/,
+                                                             float* __restrict__ dx, size_t total4) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  const int c = (int)(i % g.Cin);
-  size_t q = i / g.Cin;
+  if (i >= total4) return;
+  const int c4 = g.Cin >> 2;
+  const int c = (int)(i % c4) * 4;
+  size_t q = i / c4;
   const int xx = (int)(q % g.W); q /= g.W;
   const int yy = (int)(q % g.H);
   const int b = (int)(q / g.H);
-  float s = 0.f;
+  f32x4 s{0.f, 0.f, 0.f, 0.f};
   for (int ky = yy % g.s; ky < g.k; ky += g.s) {
     const int oy = (yy - ky) / g.s;
     if (yy < ky || oy >= g.Ho) continue;
@@ -122,10 +125,18 @@ __global__ void conv_bwd_input_kernel(const ConvG g, const float* __restrict__ d
       if (xx < kx || ox >= g.Wo) continue;
       const float* zp = dz + (((size_t)b * g.Ho + oy) * g.Wo + ox) * g.Cout;
       const float* wp = w + (size_t)((ky * g.k + kx) * g.Cin + c) * g.Cout;
-      for (int n = 0; n < g.Cout; ++n) s = fmaf(zp[n], wp[n], s);
+      for (int n = 0; n < g.Cout; n += 4) {
+        const f32x4 z = *(const f32x4*)(zp + n);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const f32x4 wv = *(const f32x4*)(wp + j * g.Cout + n);
+          s[j] = fmaf(z[0], wv[0], s[j]); s[j] = fmaf(z[1], wv[1], s[j]);
+          s[j] = fmaf(z[2], wv[2], s[j]); s[j] = fmaf(z[3], wv[3], s[j]);
+        }
+      }
     }
   }
-  dx[i] = s;
+  *(f32x4*)(dx + i * 4) = s;
 }
 
 // ---------------------------------------------------------------- weight gradient
@@ -211,16 +222,29 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ConvG g, const fl
   }
 }
 
-// grad[(k, n)] in canonical order ([K][Cout] kernel, then bias[Cout]) = sum of the slabs in order
-__global__ void conv_wgrad_reduce_kernel(const float* __restrict__ slabs, int n_slabs, int KP, int NP, int K, int Cout,
-                                         float* __restrict__ grad) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (K + 1) * Cout) return;
-  const int k = i / Cout, n = i - k * Cout;
-  const float* p = slabs + (size_t)k * NP + n;
+// grad[(k, n)] in canonical order ([K][Cout] kernel, then bias[Cout]) = sum of the slabs.  A workgroup
+// handles 16 entries; 16 threads per entry each add a strided share of the slabs in index order and the
+// 16 partial sums are added in a fixed order, so the result does not depend on timing.
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __restrict__ slabs, int n_slabs, int KP, int NP,
+                                                                int K, int Cout, float* __restrict__ grad) {
+  __shared__ float part[16][17];
+  const int e = threadIdx.x >> 4, j = threadIdx.x & 15;
+  const int i = blockIdx.x * 16 + e;
+  const int total = (K + 1) * Cout;
   float s = 0.f;
-  for (int j = 0; j < n_slabs; ++j) s += p[(size_t)j * KP * NP];
-  grad[i] = s;
+  if (i < total) {
+    const int k = i / Cout, n = i - k * Cout;
+    const float* p = slabs + (size_t)k * NP + n;
+    for (int q = j; q < n_slabs; q += 16) s += p[(size_t)q * KP * NP];
+  }
+  part[e][j] = s;
+  __syncthreads();
+  if (j == 0 && i < total) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += part[e][q];
+    grad[i] = t;
+  }
 }
 
 inline int launched() { return (int)hipGetLastError(); }
@@ -278,9 +302,9 @@ int rlgan_conv_backward_input(const rlgan_conv_t* conv, const float* dz, const f
   ConvG g;
   if (!make_conv(conv, g)) return RLGAN_E_DIMS;
   if (!dz || !w_canon || !dx || n_images <= 0) return RLGAN_E_ARG;
-  const size_t total = (size_t)n_images * g.H * g.W * g.Cin;
-  hipLaunchKernelGGL(conv_bwd_input_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     g, dz, w_canon, dx, total);
+  const size_t total4 = (size_t)n_images * g.H * g.W * (g.Cin / 4);
+  hipLaunchKernelGGL(conv_bwd_input_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     g, dz, w_canon, dx, total4);
   return launched();
 }
 
@@ -312,7 +336,7 @@ int rlgan_conv_backward_weights(const rlgan_conv_t* conv, const float* x, const 
   }
 #undef RLGAN_WG
   if (const int rc = launched()) return rc;
-  hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(cdiv((g.K + 1) * g.Cout, 256)), dim3(256), 0, st, slabs, used, KP, NP, g.K, g.Cout, grad);
+  hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(cdiv((g.K + 1) * g.Cout, 16)), dim3(256), 0, st, slabs, used, KP, NP, g.K, g.Cout, grad);
   return launched();
 }
 
