@@ -163,3 +163,42 @@ def test_vectorised_learner_runs_and_is_deterministic():
     np.testing.assert_array_equal(runs[0][3], runs[1][3])
     d = runs[0][3]
     assert set(np.unique(d[:, 0])) <= {0.0, 1.0} and (np.abs(d[:, 21:23]) <= 1).all()
+
+
+def test_vectorised_learner_tracks_the_oracle_loop():
+    """fill() + three iterations of the device loop against the NumPy restatement of the same loop
+    (oracle/loop.py): ring rows, index draws, goals, episode clocks, noise scale, losses, weights.
+    Short episodes (max_ep_steps = 4) so that resets happen inside the window."""
+    import rl_gan_amd as R
+    from gpu_util import close
+    from oracle_util import load_weights
+    from oracle.agent import CuriousAgent, Hyper
+    from oracle.loop import VecLoop
+    cfg = R.LearnerConfig(n_env=48, batch_size=40, memory_capacity=128, seed=5, max_ep_steps=4, replace_iter_a=2, replace_iter_c=3)
+    L = R.CuriousLearner(cfg)
+    ag = CuriousAgent(seed=0, hyper=Hyper(replace_iter_a=2, replace_iter_c=3))
+    load_weights(ag, {"actor_e": L.actor.e.get_flat(), "actor_t": L.actor.t.get_flat(), "critic_e": L.critic.e.get_flat(),
+                      "critic_t": L.critic.t.get_flat(), "gen": L.gen.net.get_flat(), "disc": L.disc.net.get_flat()})
+    O = VecLoop(ag, cfg.n_env, cfg.batch_size, cfg.memory_capacity, cfg.mode, L.philox_seed, cfg.seed, max_ep_steps=cfg.max_ep_steps)
+    np.testing.assert_allclose(L.env.state32.cpu().numpy(), O.state32, rtol=0, atol=1e-7)
+    L.fill()
+    while O.pointer <= O.cap:
+        O.act()
+    for it in range(3):
+        assert L.memory.pointer == O.pointer and L.ctr.tolist() == [O.pointer, O.step_count]
+        np.testing.assert_array_equal(L.idx.cpu().numpy(), O.idx)                       # bit-exact draws
+        close(L.memory._data[:, :25].cpu().numpy(), O.ring, rtol=2e-5, what=f"ring before update {it}")
+        np.testing.assert_array_equal(L.env.goal.cpu().numpy().reshape(-1, 2), O.env.goal)
+        np.testing.assert_array_equal(L.ep_t.cpu().numpy(), O.ep_t)
+        assert int(L.n_resets.item()) == O.n_resets and abs(float(L.var.item()) - O.var) < 1e-15
+        ref = O.update()
+        L.step()                     # update on the same minibatch, its losses, the next acting step, the next draw
+        O.act()
+        l = L.losses()
+        close(l["critic"], ref["critic_loss"], what=f"critic loss {it}", rtol=5e-5)
+        close(l["D_loss"], ref["D_loss"], what=f"D_loss {it}", rtol=2e-5)
+        close(l["G_loss"], ref["G_loss"], what=f"G_loss {it}", rtol=2e-5)
+    assert O.n_resets > 0
+    close(L.actor.e.get_flat(), ag.flat("actor_e"), rtol=5e-5, what="actor weights")
+    close(L.critic.e.get_flat(), ag.flat("critic_e"), rtol=5e-5, what="critic weights")
+    np.testing.assert_array_equal(L.actor.t.get_flat(), L.actor.e.get_flat())       # copied on calls 0 and 2
