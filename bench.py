@@ -45,6 +45,18 @@ MACS_PER_ROW["phase2_rows"] = MACS_PER_ROW["actor_step_rows"] + MACS_PER_ROW["ge
 PEAK_FP32_TFLOPS = 157.3   # MI355X dense fp32 matrix/vector peak
 
 
+def measured_hbm_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the newest committed counter run (profiles/*_pmc_hbm.json,
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command); None when there is none."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm.json")))
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        k = json.load(f).get("kernels", {}).get(kernel.replace("_rows", "_kernel"))
+    return k["hbm_bytes_per_launch"] if k else None
+
+
 def cpu_baseline(budget_s=12.0):
     """The oracle's float32 update at batch 4096 on the host cores (NumPy + its BLAS threads)."""
     import numpy as np
@@ -141,7 +153,7 @@ def main():
             "kernel_ms": {k: round(v, 4) for k, v in sorted(avg_ms.items())},
             "losses": {k: round(v, 6) for k, v in losses.items()},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 3), "peak": PEAK_FP32_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_TFLOPS, 4), "traffic": None},
+                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_TFLOPS, 4), "traffic": measured_hbm_traffic(dom)},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
