@@ -53,7 +53,7 @@ __device__ __forceinline__ void critic_tile(const CriticArgs& A, float* smem, in
   const ActsG wc = acts_at(A.acts_c.p, row0, A.gc.ld3);
   load_x0(t.x0, row0, A.n_rows, gin(A.s, S), gin(A.a, Ad), nil(), wc.x0);
   __syncthreads();
-  Pre<1, 1> p_cb;
+  PreAll<1> p_cb;
   net_forward<NET_CRITIC, true>(A.critic_e.wf, A.gc, t, wc, p_ce, [&] { p_cb.issue(A.critic_e.wb + A.gc.offb[3]); });
   float l = 0.f;
   if (threadIdx.x < ROWS) {
@@ -84,7 +84,7 @@ __device__ __forceinline__ void critic_tile(const CriticArgs& A, float* smem, in
     const ActsG wa = acts_at(A.acts_a.p, row0, A.ga.ld3);
     load_x0(t.x0, row0, A.n_rows, gin(A.s, S), nil(), nil(), wa.x0);
     __syncthreads();
-    Pre<1, 1> p_ab;
+    PreAll<1> p_ab;
     net_forward<NET_ACTOR, true>(A.actor_e.wf, A.ga, t, wa, p_ae, [&] { p_ab.issue(A.actor_e.wb + A.ga.offb[3]); });
     {
       const int r = threadIdx.x >> 4, c = threadIdx.x & 15;
@@ -133,14 +133,14 @@ __device__ __forceinline__ void actor_tile(const ActorArgs& A, float* smem, int 
   net_forward<NET_ACTOR, true>(A.actor_e.wf, A.ga, ta, wa, p_a, [&] { p_c.issue(A.critic_e.wf + A.gc.offf[0]); });   // a = actor_eval(s), live
   load_x0(tc.x0, row0, A.n_rows, gin(A.s, S), lin(ta.out, LD_O, Ad), nil(), nullptr);
   __syncthreads();
-  Pre<1, 1> p_cb;
+  PreAll<1> p_cb;
   net_forward<NET_CRITIC, false>(A.critic_e.wf, A.gc, tc, none, p_c, [&] { p_cb.issue(A.critic_e.wb + A.gc.offb[3]); });
   {
     const int r = threadIdx.x >> 4, c = threadIdx.x & 15;
     tc.out[r * LD_O + c] = (c == 0 && row0 + r < A.n_rows) ? 1.f : 0.f;   // d(sum_b q_b)/dq = 1, DDPG.py:151
   }
   __syncthreads();
-  Pre<1, 1> p_ab;
+  PreAll<1> p_ab;
   net_backward<NET_CRITIC, true, false>(A.critic_e.wb, A.gc, tc, none, p_cb, [&] { p_ab.issue(A.actor_e.wb + A.ga.offb[3]); });
   {
     const int r = threadIdx.x >> 4, c = threadIdx.x & 15;
@@ -190,7 +190,7 @@ __device__ __forceinline__ void disc_tile(const DiscArgs& A, float* smem, int ti
     const ActsG wd = acts_at(A.acts_d.p, pass * A.rows16 + row0, A.gd.ld3);
     load_x0(t.x0, row0, A.n_rows, gin(A.s, S), gin(pass == 0 ? A.g : A.s_next, S), gin(A.a, Ad), wd.x0);
     __syncthreads();
-    Pre<1, 1> p_b;
+    PreAll<1> p_b;
     net_forward<NET_DISC, true>(A.disc.wf, A.gd, t, wd, p_f, [&] { p_b.issue(A.disc.wb + A.gd.offb[3]); });
     const float label = pass == 0 ? 0.f : A.label_real;
     float l = 0.f;
@@ -247,7 +247,7 @@ __device__ __forceinline__ void gen_tile(const GenArgs& A, float* smem, int tile
   net_forward<NET_GEN, true>(A.gen.wf, A.gg, tg, wg, p_g, [&] { p_d.issue(A.disc.wf + A.gd.offf[0]); });   // g^ = G(s, a), live
   load_x0(td.x0, row0, A.n_rows, gin(A.s, S), lin(tg.out, LD_O, S), gin(A.a, Ad), nullptr);
   __syncthreads();
-  Pre<1, 1> p_db;
+  PreAll<1> p_db;
   net_forward<NET_DISC, false>(A.disc.wf, A.gd, td, none, p_d, [&] { p_db.issue(A.disc.wb + A.gd.offb[3]); });
   float l = 0.f;
   if (threadIdx.x < ROWS) {

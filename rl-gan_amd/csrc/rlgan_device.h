@@ -120,7 +120,7 @@ template <> struct NetT<NET_GEN>    { static constexpr int A1 = ACT_RELU,  A2 = 
 template <> struct NetT<NET_DISC>   { static constexpr int A1 = ACT_LRELU, A2 = ACT_LRELU, A3 = ACT_LRELU, A4 = ACT_LINEAR, NT3 = 1, L3 = 20; };
 
 // ---------------------------------------------------------------- LDS carve (floats)
-constexpr int PART_FLOATS = 0;                       // (no partial-sum staging: every tile belongs to one wave)
+constexpr int PART_FLOATS = 4 * ROWS * 20;           // four waves' 16x16 partial sums of a chained layer
 constexpr int WIDE_FLOATS = ROWS * LD_W;
 constexpr int T3_FLOATS = ROWS * LD_3W;              // h3 tile (16 or 64 columns)
 constexpr int X0_FLOATS = ROWS * LD_X0;
@@ -128,6 +128,7 @@ constexpr int O_FLOATS = ROWS * LD_O;
 #ifndef RLGAN_GD
 #define RLGAN_GD 2
 #endif
+
 constexpr int GD = RLGAN_GD;                         // k-groups of operands kept in flight per wave
 
 __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
@@ -250,6 +251,103 @@ __device__ __forceinline__ void dense_tiles(Pre<NT, NG>& p, const float* xq, int
   }
 }
 
+// A wave's tiles of a one-k-group layer whose A operand (all 16 rows, the 16 k of the group) the wave
+// already holds in registers.
+template <int NT, int T, class P, class F, class X>
+__device__ __forceinline__ void rega_tiles(Pre<NT, 1>& p, const f32x4 a, int r0, int c0, P pre, F f, float* gdst, X next) {
+  float hv[T][4];
+#pragma unroll
+  for (int i = 0; i < T; ++i) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) hv[i][r] = pre(r0 + r, 16 * (p.w + 4 * i) + c0);
+  }
+  f32x4 acc[T];
+#pragma unroll
+  for (int i = 0; i < T; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+#pragma unroll
+    for (int i = 0; i < T; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], p.b[0][i][m], acc[i], 0, 0, 0);
+  }
+  next();
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < T; ++i) {
+    const int col = 16 * (p.w + 4 * i) + c0;
+    f32x4 v;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = f(r0 + r, col, acc[i][r], hv[i][r]);
+    if (gdst) *(f32x4*)(gdst + col * 16 + r0) = v;
+  }
+}
+template <int NT, class P, class F, class X>
+__device__ __forceinline__ void dense16_rega(Pre<NT, 1>& p, const f32x4 a, P pre, F f, float* gdst, X next) {
+  using Q = Pre<NT, 1>;
+  const int lane = threadIdx.x & 63;
+  const int r0 = (lane >> 4) * 4, c0 = lane & 15;
+  if constexpr (Q::NHEAVY == 0) rega_tiles<NT, Q::TMAX>(p, a, r0, c0, pre, f, gdst, next);
+  else if (p.w < Q::NHEAVY) rega_tiles<NT, Q::TMAX>(p, a, r0, c0, pre, f, gdst, next);
+  else if constexpr (Q::TMIN > 0) rega_tiles<NT, Q::TMIN>(p, a, r0, c0, pre, f, gdst, next);
+  else next();
+  lds_barrier();
+}
+
+// ---------------------------------------------------------------- chaining into a one-tile layer
+// A layer that follows a wide one and has a single column tile (N <= 16) needs all of the wide
+// layer's output as its K range.  Instead of a stage of its own it is split over K along the tiles of
+// the wide layer: right after its epilogue a wave multiplies the output tiles it has just written to
+// LDS (reading them back as A operands needs no workgroup barrier: a wave's LDS operations execute in
+// order) with the matching k-groups of the narrow layer's weights, and leaves a 16x16 partial sum in
+// `part`; the workgroup barrier that ends the wide layer then covers both, and whoever needs the
+// narrow layer's output adds the four partial sums in wave order.
+constexpr int LDP = 20;                               // row stride of a partial-sum tile
+struct NoChain {
+  static constexpr bool active = false;
+  template <int T> __device__ __forceinline__ void run(int, const float*, int) const {}
+};
+template <int TMAX>
+struct Chain {
+  static constexpr bool active = true;
+  f32x4 wc[TMAX];                                      // narrow layer's fragments of the k-groups w, w+4, ...
+  float* part;                                         // [4 waves][16][LDP]
+  // wn: fragment image of the narrow layer (one column tile); ng: its number of k-groups
+  __device__ __forceinline__ void issue(const float* __restrict__ wn, int ng, int w) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int i = 0; i < TMAX; ++i) wc[i] = *(const f32x4*)(wn + (min(w + 4 * i, ng - 1) * 64 + lane) * 4);
+  }
+  // xs: the wide layer's output tile in LDS (row stride ldx); this wave owns its column tiles w, w+4, ...
+  template <int T>
+  __device__ __forceinline__ void run(int w, const float* xs, int ldx) {
+    const int lane = threadIdx.x & 63;
+    const int r0 = (lane >> 4) * 4, c0 = lane & 15;
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    f32x4 a[T];
+#pragma unroll
+    for (int i = 0; i < T; ++i) a[i] = *(const f32x4*)(xs + c0 * ldx + r0 + 16 * (w + 4 * i));
+#pragma unroll
+    for (int i = 0; i < T; ++i) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m) acc[i & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][m], wc[i][m], acc[i & 1], 0, 0, 0);
+    }
+    const f32x4 z = acc[0] + acc[1];
+    float* pw = part + w * (ROWS * LDP) + r0 * LDP + c0;   // slot = tile owner, whatever wave that is in this workgroup
+#pragma unroll
+    for (int r = 0; r < 4; ++r) pw[r * LDP] = z[r];
+  }
+};
+// sum of the four waves' partial tiles at (row, col .. col+3), in wave order
+__device__ __forceinline__ f32x4 chain_sum4(const float* part, int row, int col) {
+  const float* q = part + row * LDP + col;
+  constexpr int WS = ROWS * LDP;
+  return ((*(const f32x4*)q + *(const f32x4*)(q + WS)) + *(const f32x4*)(q + 2 * WS)) + *(const f32x4*)(q + 3 * WS);
+}
+__device__ __forceinline__ float chain_sum1(const float* part, int row, int col) {
+  const float* q = part + row * LDP + col;
+  constexpr int WS = ROWS * LDP;
+  return ((q[0] + q[WS]) + q[2 * WS]) + q[3 * WS];
+}
+
 // One dense layer of a 16-row tile, Z[16, NT*16] = X[16, NG*16] * fragments.
 //   p     the layer's weight fragments, already requested with p.issue()
 //   xs    the input tile in LDS (row stride ldx, at least NG*16 valid columns)
@@ -260,9 +358,11 @@ __device__ __forceinline__ void dense_tiles(Pre<NT, NG>& p, const float* xq, int
 //         out [column][16 rows] (one 16-byte store per lane and column)
 //   next  called by every wave between its last MFMA and its epilogue: the place to issue() the next
 //         layer's Pre
+//   chain / ys, ldy: optional chained one-tile layer (see Chain); ys is the LDS tile f writes
 // Ends with a workgroup barrier on LDS (what the epilogues wrote is visible to every wave after it).
-template <int NT, int NG, class P, class F, class X>
-__device__ __forceinline__ void dense16(Pre<NT, NG>& p, const float* xs, int ldx, float*, P pre, F f, float* gdst, X next) {
+template <int NT, int NG, class P, class F, class X, class CH>
+__device__ __forceinline__ void dense16(Pre<NT, NG>& p, const float* xs, int ldx, P pre, F f, float* gdst, X next,
+                                        CH& chain, const float* ys, int ldy) {
   using Q = Pre<NT, NG>;
   const int lane = threadIdx.x & 63;
   const int r0 = (lane >> 4) * 4, c0 = lane & 15;
@@ -270,15 +370,40 @@ __device__ __forceinline__ void dense16(Pre<NT, NG>& p, const float* xs, int ldx
   STAMP(1);
   if constexpr (Q::NHEAVY == 0) {
     dense_tiles<NT, NG, Q::TMAX>(p, xq, r0, c0, pre, f, gdst, next);
+    if constexpr (CH::active) chain.template run<Q::TMAX>(p.w, ys, ldy);
   } else {
-    if (p.w < Q::NHEAVY) dense_tiles<NT, NG, Q::TMAX>(p, xq, r0, c0, pre, f, gdst, next);
-    else if constexpr (Q::TMIN > 0) dense_tiles<NT, NG, Q::TMIN>(p, xq, r0, c0, pre, f, gdst, next);
-    else next();
+    if (p.w < Q::NHEAVY) {
+      dense_tiles<NT, NG, Q::TMAX>(p, xq, r0, c0, pre, f, gdst, next);
+      if constexpr (CH::active) chain.template run<Q::TMAX>(p.w, ys, ldy);
+    } else if constexpr (Q::TMIN > 0) {
+      dense_tiles<NT, NG, Q::TMIN>(p, xq, r0, c0, pre, f, gdst, next);
+      if constexpr (CH::active) chain.template run<Q::TMIN>(p.w, ys, ldy);
+    } else {
+      next();
+      static_assert(!CH::active || Q::TMIN > 0, "a chained layer needs a tile on every wave");
+    }
   }
   STAMP(4);
   lds_barrier();
   STAMP(5);
 }
+template <int NT, int NG, class P, class F, class X>
+__device__ __forceinline__ void dense16(Pre<NT, NG>& p, const float* xs, int ldx, P pre, F f, float* gdst, X next) {
+  NoChain nc;
+  dense16(p, xs, ldx, pre, f, gdst, next, nc, nullptr, 0);
+}
+
+// the fragments of a one-tile layer (NG k-groups), loaded by EVERY wave: for layers so small that each
+// wave computes them for itself rather than wait for another wave's result
+template <int NG>
+struct PreAll {
+  f32x4 b[NG];
+  __device__ __forceinline__ void issue(const float* __restrict__ wp) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) b[g] = *(const f32x4*)(wp + (g * 64 + lane) * 4);
+  }
+};
 
 // LDS tiles of one network for one 16-row tile
 struct Tiles {
@@ -287,7 +412,7 @@ struct Tiles {
   float* h2;   // [16][LD_W]
   float* h3;   // [16][LD_3W or LD_O]
   float* out;  // [16][LD_O]
-  float* part; // PART_FLOATS
+  float* part; // PART_FLOATS: partial sums of chained layers
 };
 
 // global work arrays of one network, already offset to this 16-row tile (or all null).  Inside a
@@ -297,70 +422,136 @@ struct ActsG {
   float* x0; float* h1; float* h2; float* h3; float* dz1; float* dz2; float* dz3; float* dz4;
 };
 
+// what the caller of net_backward requests ahead for its first stage: the fragments of W4^T
+template <int KIND> struct BwdFirst { using type = PreAll<1>; };
+template <> struct BwdFirst<NET_GEN> { using type = Pre<4, 1>; };
+template <int KIND> using BwdPre = typename BwdFirst<KIND>::type;
+
 // forward pass of a whole network for the tile in t.x0; activations stay in t.h1..t.out and, when
 // STORE, are also written to the global work arrays for the weight-gradient pass.  `p1` holds the
-// first layer's fragments (issue()d by the caller, ideally well before); `next` is called before the
-// last layer's epilogue so the caller can request the fragments of whatever runs after this network.
+// first layer's fragments (issue()d by the caller, ideally well before); `next` is called late in the
+// pass so the caller can request the fragments of whatever runs after this network.
+//   networks with a 10-wide third layer:  L1 | L2 + L3 partial sums (chained) | one wave: L3 total, L4
+//   generator (50-wide third layer):      L1 | L2 | L3 + L4 partial sums (chained) | L4 total
 template <int KIND, bool STORE, class X>
 __device__ __forceinline__ void net_forward(const float* __restrict__ wf, const Geo& g, const Tiles& t, const ActsG& ws,
                                             Pre<NT_H, 2>& p1, X next) {
   using N = NetT<KIND>;
   constexpr int L3 = N::L3, NT3 = N::NT3;
   float* h1 = t.h1; float* h2 = t.h2; float* h3 = t.h3; float* out = t.out;
+  const int lane = threadIdx.x & 63;
+  const int n3 = g.N3, nout = g.NOUT;
   Pre<NT_H, NT_H> p2;
-  dense16(p1, t.x0, LD_X0, t.part, NoPre{}, [=](int r, int c, float z, float) {
+  dense16(p1, t.x0, LD_X0, NoPre{}, [=](int r, int c, float z, float) {
     const float v = c < HID ? act_f<N::A1>(z) : (c == HID ? 1.f : 0.f);
     h1[r * LD_W + c] = v;
     return v;
   }, STORE ? ws.h1 : nullptr, [&] { p2.issue(wf + g.offf[1]); });
-  Pre<NT3, NT_H> p3;
-  dense16(p2, h1, LD_W, t.part, NoPre{}, [=](int r, int c, float z, float) {
+  auto f2 = [=](int r, int c, float z, float) {
     const float v = c < HID ? act_f<N::A2>(z) : (c == HID ? 1.f : 0.f);
     h2[r * LD_W + c] = v;
     return v;
-  }, STORE ? ws.h2 : nullptr, [&] { p3.issue(wf + g.offf[2]); });
-  const int n3 = g.N3;
-  Pre<1, NT3> p4;
-  dense16(p3, h2, LD_W, t.part, NoPre{}, [=](int r, int c, float z, float) {
-    const float v = c < n3 ? act_f<N::A3>(z) : (c == n3 ? 1.f : 0.f);
-    h3[r * L3 + c] = v;
-    return v;
-  }, STORE ? ws.h3 : nullptr, [&] { p4.issue(wf + g.offf[3]); });
-  const int nout = g.NOUT;
-  dense16(p4, h3, L3, t.part, NoPre{}, [=](int r, int c, float z, float) {
-    const float v = c < nout ? act_f<N::A4>(z) : 0.f;
-    out[r * LD_O + c] = v;
-    return v;
-  }, nullptr, next);
+  };
+  if constexpr (NT3 == 1) {
+    Chain<Pre<NT_H, NT_H>::TMAX> ch;
+    ch.part = t.part;
+    PreAll<1> p4;
+    dense16(p2, h1, LD_W, NoPre{}, f2, STORE ? ws.h2 : nullptr,
+            [&] { ch.issue(wf + g.offf[2], NT_H, p2.w); p4.issue(wf + g.offf[3]); }, ch, h2, LD_W);
+    next();
+    if (wave_id() == 0) {
+      // third layer: total of the partial sums, activation; the lane holds row l&15, columns 4q..4q+3,
+      // which is the A operand of the fourth layer
+      const int row = lane & 15, k0 = (lane >> 4) * 4;
+      const f32x4 s = chain_sum4(t.part, row, k0);
+      f32x4 v;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = k0 + r < n3 ? act_f<N::A3>(s[r]) : (k0 + r == n3 ? 1.f : 0.f);
+      *(f32x4*)(h3 + row * L3 + k0) = v;
+      if (STORE) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ws.h3[(k0 + r) * 16 + row] = v[r];
+      }
+      f32x4 acc{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int m = 0; m < 4; ++m) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(v[m], p4.b[0][m], acc, 0, 0, 0);
+      const int r0 = (lane >> 4) * 4, c0 = lane & 15;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) out[(r0 + r) * LD_O + c0] = c0 < nout ? act_f<N::A4>(acc[r]) : 0.f;
+    }
+    lds_barrier();
+  } else {
+    Pre<NT3, NT_H> p3;
+    dense16(p2, h1, LD_W, NoPre{}, f2, STORE ? ws.h2 : nullptr, [&] { p3.issue(wf + g.offf[2]); });
+    Chain<1> ch;
+    ch.part = t.part;
+    dense16(p3, h2, LD_W, NoPre{}, [=](int r, int c, float z, float) {
+      const float v = c < n3 ? act_f<N::A3>(z) : (c == n3 ? 1.f : 0.f);
+      h3[r * L3 + c] = v;
+      return v;
+    }, STORE ? ws.h3 : nullptr, [&] { ch.issue(wf + g.offf[3], NT3, p3.w); }, ch, h3, L3);
+    next();
+    {
+      const int r = threadIdx.x >> 4, c = threadIdx.x & 15;
+      const float z = chain_sum1(t.part, r, c);
+      out[r * LD_O + c] = c < nout ? act_f<N::A4>(z) : 0.f;
+    }
+    lds_barrier();
+  }
 }
 
 // backward pass: t.out must hold dL/dz4 ([16][LD_O], zeros beyond NOUT), t.h1..h3 the forward
-// activations.  Each layer's dz overwrites its activation tile in place and, when STORE, is written to
-// the global work arrays.  With NEED_DX0 the gradient w.r.t. the network inputs is left in t.x0
-// (columns 0..K0-1, stride LD_X0).  `p4` / `next` as in net_forward (p4 = fragments of W4^T).
+// activations.  dz1 and dz2 overwrite h1 and h2 in place and, when STORE, all dz are written to the
+// global work arrays.  With NEED_DX0 the gradient w.r.t. the network inputs is left in t.x0 (columns
+// 0..15, stride LD_X0).  `p4` = fragments of W4^T requested by the caller, `next` as in net_forward.
+//   10-wide third layer: every wave computes dz3 for itself (four MFMAs with swapped operands leave it
+//   in A-operand layout in registers), then its tiles of dz2 | dz1 (+ chained dX0 partial sums) | dX0 total
 template <int KIND, bool NEED_DX0, bool STORE, class X>
 __device__ __forceinline__ void net_backward(const float* __restrict__ wb, const Geo& g, const Tiles& t, const ActsG& ws,
-                                             Pre<NetT<KIND>::NT3, 1>& p4, X next) {
+                                             BwdPre<KIND>& p4, X next) {
   using N = NetT<KIND>;
   constexpr int L3 = N::L3, NT3 = N::NT3;
   float* h1 = t.h1; float* h2 = t.h2; float* h3 = t.h3; float* x0 = t.x0;
+  const int lane = threadIdx.x & 63;
+  const int r0 = (lane >> 4) * 4, c0 = lane & 15;
   if (STORE) {
     const int r = threadIdx.x >> 4, c = threadIdx.x & 15;
     ws.dz4[c * 16 + r] = t.out[r * LD_O + c];
   }
   const int n3 = g.N3;
   Pre<NT_H, NT3> p3;
-  dense16(p4, t.out, LD_O, t.part, [=](int r, int c) { return h3[r * L3 + c]; }, [=](int r, int c, float z, float h) {
-    const float v = c < n3 ? z * act_d<N::A3>(h) : 0.f;
-    h3[r * L3 + c] = v;
-    return v;
-  }, STORE ? ws.dz3 : nullptr, [&] { p3.issue(wb + g.offb[2]); });
+  p3.issue(wb + g.offb[2]);
   Pre<NT_H, NT_H> p2;
-  dense16(p3, h3, L3, t.part, [=](int r, int c) { return h2[r * LD_W + c]; }, [=](int r, int c, float z, float h) {
+  auto f2 = [=](int r, int c, float z, float h) {
     const float v = c < HID ? z * act_d<N::A2>(h) : 0.f;
     h2[r * LD_W + c] = v;
     return v;
-  }, STORE ? ws.dz2 : nullptr, [&] { p2.issue(wb + g.offb[1]); });
+  };
+  auto g2 = [=](int r, int c) { return h2[r * LD_W + c]; };
+  if constexpr (NT3 == 1) {
+    // dH3^T = W4 * dZ4^T: the operands trade places, so the lane gets row l&15, columns 4q..4q+3 of dH3
+    const f32x4 a4 = *(const f32x4*)(t.out + c0 * LD_O + r0);
+    const f32x4 hv = *(const f32x4*)(h3 + c0 * L3 + r0);
+    f32x4 d{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int m = 0; m < 4; ++m) d = __builtin_amdgcn_mfma_f32_16x16x4f32(p4.b[0][m], a4[m], d, 0, 0, 0);
+    f32x4 dz3;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dz3[r] = r0 + r < n3 ? d[r] * act_d<N::A3>(hv[r]) : 0.f;
+    if (STORE && wave_id() == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ws.dz3[(r0 + r) * 16 + c0] = dz3[r];
+    }
+    // dz2 tiles of this wave: one k-group, its A operand is dz3 in registers
+    dense16_rega(p3, dz3, g2, f2, STORE ? ws.dz2 : nullptr, [&] { p2.issue(wb + g.offb[1]); });
+  } else {
+    dense16(p4, t.out, LD_O, [=](int r, int c) { return h3[r * L3 + c]; }, [=](int r, int c, float z, float h) {
+      const float v = c < n3 ? z * act_d<N::A3>(h) : 0.f;
+      h3[r * L3 + c] = v;
+      return v;
+    }, STORE ? ws.dz3 : nullptr, NoNext{});
+    dense16(p3, h3, L3, g2, f2, STORE ? ws.dz2 : nullptr, [&] { p2.issue(wb + g.offb[1]); });
+  }
   auto f1 = [=](int r, int c, float z, float h) {
     const float v = c < HID ? z * act_d<N::A1>(h) : 0.f;
     h1[r * LD_W + c] = v;
@@ -368,11 +559,17 @@ __device__ __forceinline__ void net_backward(const float* __restrict__ wb, const
   };
   auto g1 = [=](int r, int c) { return h1[r * LD_W + c]; };
   if constexpr (NEED_DX0) {
-    Pre<1, NT_H> p1;
-    dense16(p2, h2, LD_W, t.part, g1, f1, STORE ? ws.dz1 : nullptr, [&] { p1.issue(wb + g.offb[0]); });
-    dense16(p1, h1, LD_W, t.part, NoPre{}, [=](int r, int c, float z, float) { x0[r * LD_X0 + c] = z; return z; }, nullptr, next);
+    Chain<Pre<NT_H, NT_H>::TMAX> ch;
+    ch.part = t.part;
+    dense16(p2, h2, LD_W, g1, f1, STORE ? ws.dz1 : nullptr, [&] { ch.issue(wb + g.offb[0], NT_H, p2.w); }, ch, h1, LD_W);
+    next();
+    {
+      const int r = threadIdx.x >> 4, c = threadIdx.x & 15;
+      x0[r * LD_X0 + c] = chain_sum1(t.part, r, c);
+    }
+    lds_barrier();
   } else {
-    dense16(p2, h2, LD_W, t.part, g1, f1, STORE ? ws.dz1 : nullptr, next);
+    dense16(p2, h2, LD_W, g1, f1, STORE ? ws.dz1 : nullptr, next);
   }
 }
 

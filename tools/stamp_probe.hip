@@ -25,7 +25,7 @@ __global__ __launch_bounds__(THREADS) void probe_kernel(const Args A) {
   __syncthreads();
   STAMP(101);
   const ActsG ws = acts_at((const float* const*)A.acts, row0, A.g.ld3);
-  Pre<1, 1> pb;
+  PreAll<1> pb;
   net_forward<NET_ACTOR, true>(A.wf, A.g, t, ws, p1, [&] { pb.issue(A.wb + A.g.offb[3]); });
   STAMP(102);
   {
