@@ -448,8 +448,13 @@ __global__ __launch_bounds__(THREADS) void wpass_kernel(const WArgs A) {
   WItem it = A.it[0];
 #pragma unroll
   for (int i = 1; i < MAX_WITEMS; ++i) if (item == i) it = A.it[i];
+  // Workgroups go to the eight XCDs round-robin (blockIdx % 8), each with its own L2.  All strips of a
+  // batch chunk read the same dZ rows, so a chunk is kept on one XCD: items start at a multiple of 8
+  // and their chunk counts are padded to a multiple of 8 (workgroups of the padding exit).
   const int local = blockIdx.x - it.blk0;
-  const int strip = local % it.nstrips, chunk = local / it.nstrips;
+  const int xcd = local & 7, j = local >> 3;
+  const int strip = j % it.nstrips, chunk = xcd + 8 * (j / it.nstrips);
+  if (chunk * it.groups_per_chunk >= it.n_groups) return;
   if (it.nt == NT_H) wpass_body<NT_H>(it, strip, chunk, part);
   else if (it.nt == 4) wpass_body<4>(it, strip, chunk, part);
   else wpass_body<1>(it, strip, chunk, part);
@@ -752,7 +757,7 @@ int rlgan_weight_grads(const rlgan_wgrad_job_t* jobs, int n_jobs, int s_dim, int
       it.ldx = ldx[l]; it.ldz = ldz[l]; it.nstrips = g.kp[l] / 16; it.nt = g.ntf[l]; it.np = g.np[l];
       it.n_groups = J.rows / ROWS; it.groups_per_chunk = cr / ROWS; it.gstride = g.gpad_floats;
       it.blk0 = b;
-      b += it.nstrips * nc;
+      b += it.nstrips * (cdiv(nc, 8) * 8);          // a multiple of 8: see the XCD mapping in wpass_kernel
     }
   }
   hipLaunchKernelGGL(wpass_kernel, dim3(b), dim3(THREADS), 0, (hipStream_t)stream, A);
