@@ -161,6 +161,23 @@ __device__ __forceinline__ void stamp_here(int tag) {
 #define STAMP(tag)
 #endif
 
+// Weight fragments are fetched with buffer loads: the address is a scalar base (resource), a per-lane
+// byte offset that never changes, and a scalar offset per (k-group, tile) -- no vector ALU work per
+// load, which matters because vector ALU instructions do not overlap with MFMAs on the same SIMD.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+struct FragSrc {
+  __amdgpu_buffer_rsrc_t rs;
+  int voff;                                            // this lane's byte offset inside a fragment block
+  __device__ __forceinline__ void set(const float* base, int first_block) {
+    rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
+    voff = (first_block * 64 + (int)(threadIdx.x & 63)) * 16;
+  }
+  // the 16-byte fragment of this lane in block `block` (blocks of 64 lanes x 16 bytes) past first_block
+  __device__ __forceinline__ f32x4 load(int block) const {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, block * 1024, 0));
+  }
+};
+
 // ---------------------------------------------------------------- weight fragments requested ahead
 // Column tiles of a layer are dealt to the four waves round-robin: the wave with rotated index w owns
 // tiles w, w+4, w+8, ...  (NT%4 waves own one tile more than the others; with fewer than four tiles
@@ -173,7 +190,7 @@ struct Pre {
   static constexpr int TMAX = (NT + 3) / 4, TMIN = NT / 4, NHEAVY = NT % 4;
   static constexpr int D = NG < GD ? NG : GD;          // groups in flight
   f32x4 b[D][TMAX];
-  const float* wl;                                     // this lane's fragment address: own tile 0, group 0
+  FragSrc src;                                         // fragment blocks counted from this wave's tile 0, group 0
   int w;                                               // rotated wave index
 
   template <int T>
@@ -181,13 +198,12 @@ struct Pre {
 #pragma unroll
     for (int g = 0; g < D; ++g) {
 #pragma unroll
-      for (int i = 0; i < T; ++i) b[g][i] = *(const f32x4*)(wl + (g * NT + 4 * i) * 256);
+      for (int i = 0; i < T; ++i) b[g][i] = src.load(g * NT + 4 * i);
     }
   }
   __device__ __forceinline__ void issue(const float* __restrict__ wp) {
-    const int lane = threadIdx.x & 63;
     w = (wave_id() + (int)blockIdx.x) & 3;
-    wl = wp + (w * 64 + lane) * 4;
+    src.set(wp, w);
     if constexpr (NHEAVY == 0) load_first<TMAX>();
     else if (w < NHEAVY) load_first<TMAX>();
     else if constexpr (TMIN > 0) load_first<TMIN>();
@@ -229,7 +245,7 @@ __device__ __forceinline__ void dense_tiles(Pre<NT, NG>& p, const float* xq, int
     }
     if (g + D < NG) {
 #pragma unroll
-      for (int i = 0; i < T; ++i) p.b[sl][i] = *(const f32x4*)(p.wl + ((g + D) * NT + 4 * i) * 256);
+      for (int i = 0; i < T; ++i) p.b[sl][i] = p.src.load((g + D) * NT + 4 * i);
       am[sl] = *(const f32x4*)(xq + 16 * (g + D));
     }
     // keep the refill D groups ahead of its use: the scheduler would otherwise sink these loads next
@@ -312,9 +328,10 @@ struct Chain {
   float* part;                                         // [4 waves][16][LDP]
   // wn: fragment image of the narrow layer (one column tile); ng: its number of k-groups
   __device__ __forceinline__ void issue(const float* __restrict__ wn, int ng, int w) {
-    const int lane = threadIdx.x & 63;
+    FragSrc src;
+    src.set(wn, 0);
 #pragma unroll
-    for (int i = 0; i < TMAX; ++i) wc[i] = *(const f32x4*)(wn + (min(w + 4 * i, ng - 1) * 64 + lane) * 4);
+    for (int i = 0; i < TMAX; ++i) wc[i] = src.load(min(w + 4 * i, ng - 1));
   }
   // xs: the wide layer's output tile in LDS (row stride ldx); this wave owns its column tiles w, w+4, ...
   template <int T>
@@ -399,9 +416,10 @@ template <int NG>
 struct PreAll {
   f32x4 b[NG];
   __device__ __forceinline__ void issue(const float* __restrict__ wp) {
-    const int lane = threadIdx.x & 63;
+    FragSrc src;
+    src.set(wp, 0);
 #pragma unroll
-    for (int g = 0; g < NG; ++g) b[g] = *(const f32x4*)(wp + (g * 64 + lane) * 4);
+    for (int g = 0; g < NG; ++g) b[g] = src.load(g);
   }
 };
 
