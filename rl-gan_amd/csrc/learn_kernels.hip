@@ -342,11 +342,13 @@ struct WItem {
 };
 struct WArgs { WItem it[MAX_WITEMS]; int n_items; };
 
-// acc[i] += X[groups g0..g1, strip]^T * dZ[groups g0..g1, tile i].  xq / zq: this lane's float4 address
-// in group 0 (work arrays are [group][column][16 rows]: lane (q, j) reads rows 4q..4q+3 of column j).
+// acc[i] += X[groups g0..g1, strip]^T * dZ[groups g0..g1, tile i].  xsrc / zsrc: buffer sources whose
+// lane offset addresses this lane's float4 in group 0 (work arrays are [group][column][16 rows]: lane
+// (q, j) reads rows 4q..4q+3 of column j); xs / zs: bytes between groups.  Buffer loads keep the address
+// arithmetic on the scalar unit (vector ALU work would not overlap with the MFMAs).
 template <int T>
-__device__ __forceinline__ void wgrad_pipe(f32x4 (&acc)[T], const float* __restrict__ xq, int xs,
-                                           const float* __restrict__ zq, int zs, int g0, int g1) {
+__device__ __forceinline__ void wgrad_pipe(f32x4 (&acc)[T], const FragSrc& xsrc, int xs, const FragSrc& zsrc, int zs,
+                                           int g0, int g1) {
   const int n = g1 - g0;
   if (n <= 0) return;
   const int nblk = (n + WD - 1) / WD;
@@ -356,10 +358,10 @@ __device__ __forceinline__ void wgrad_pipe(f32x4 (&acc)[T], const float* __restr
 #pragma unroll
   for (int j = 0; j < WD; ++j) {
     const int g = g0 + j, gc = min(g, last);
-    const f32x4 av = *(const f32x4*)(xq + (size_t)gc * xs);
+    const f32x4 av = xsrc.load_at(gc * xs);
     a[j] = g < g1 ? av : zero;
 #pragma unroll
-    for (int i = 0; i < T; ++i) b[j][i] = *(const f32x4*)(zq + (size_t)gc * zs + i * 256);
+    for (int i = 0; i < T; ++i) b[j][i] = zsrc.load_at(gc * zs + i * 1024);
   }
   for (int blk = 1; blk < nblk; ++blk) {
 #pragma unroll
@@ -370,10 +372,10 @@ __device__ __forceinline__ void wgrad_pipe(f32x4 (&acc)[T], const float* __restr
         for (int i = 0; i < T; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][m], b[j][i][m], acc[i], 0, 0, 0);
       }
       const int g = g0 + blk * WD + j, gc = min(g, last);
-      const f32x4 av = *(const f32x4*)(xq + (size_t)gc * xs);
+      const f32x4 av = xsrc.load_at(gc * xs);
       a[j] = g < g1 ? av : zero;
 #pragma unroll
-      for (int i = 0; i < T; ++i) b[j][i] = *(const f32x4*)(zq + (size_t)gc * zs + i * 256);
+      for (int i = 0; i < T; ++i) b[j][i] = zsrc.load_at(gc * zs + i * 1024);
       __builtin_amdgcn_sched_barrier(0);   // keep the refill WD groups ahead of its use
     }
   }
@@ -397,9 +399,11 @@ __device__ __forceinline__ void wpass_body(const WItem& it, int strip, int chunk
   const int q4 = (lane >> 4) * 4, j = lane & 15;
   const int gb = chunk * it.groups_per_chunk;
   const int ge = min(it.n_groups, gb + it.groups_per_chunk);
-  const int xs = it.ldx * 16, zs = it.ldz * 16;
-  const float* xq = it.X + (16 * strip + j) * 16 + q4;
-  const float* zq = it.dZ + j * 16 + q4;
+  const int xs = it.ldx * 64, zs = it.ldz * 64;            // bytes per 16-row group
+  FragSrc xsrc, zsrc_t, zsrc_r;
+  xsrc.set_bytes(it.X, ((16 * strip + j) * 16 + q4) * 4);
+  zsrc_t.set_bytes(it.dZ, (j * 16 + q4 + (wave * TPW) * 256) * 4);
+  zsrc_r.set_bytes(it.dZ, (j * 16 + q4 + (4 * TPW) * 256) * 4);
   float* gout = it.gout + (size_t)chunk * it.gstride + (size_t)(16 * strip) * it.np;
   if constexpr (REM > 0) {
     const int per = (it.groups_per_chunk + 3) >> 2;
@@ -407,7 +411,7 @@ __device__ __forceinline__ void wpass_body(const WItem& it, int strip, int chunk
     f32x4 accr[REM];
 #pragma unroll
     for (int i = 0; i < REM; ++i) accr[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    wgrad_pipe<REM>(accr, xq, xs, zq + (4 * TPW) * 256, zs, w0, w1);
+    wgrad_pipe<REM>(accr, xsrc, xs, zsrc_r, zs, w0, w1);
     float* pw = part + wave * ROWS * LDP + q4 * LDP + j;
 #pragma unroll
     for (int i = 0; i < REM; ++i) {
@@ -419,7 +423,7 @@ __device__ __forceinline__ void wpass_body(const WItem& it, int strip, int chunk
     f32x4 acc[TPW];
 #pragma unroll
     for (int i = 0; i < TPW; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    wgrad_pipe<TPW>(acc, xq, xs, zq + (wave * TPW) * 256, zs, gb, ge);
+    wgrad_pipe<TPW>(acc, xsrc, xs, zsrc_t, zs, gb, ge);
 #pragma unroll
     for (int i = 0; i < TPW; ++i) {
       const int col = 16 * (wave * TPW + i) + j;

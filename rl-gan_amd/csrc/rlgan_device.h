@@ -176,6 +176,14 @@ struct FragSrc {
   __device__ __forceinline__ f32x4 load(int block) const {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, block * 1024, 0));
   }
+  // general form: lane byte offset `lane_bytes` fixed at set-up, uniform byte offset per load
+  __device__ __forceinline__ void set_bytes(const float* base, int lane_bytes) {
+    rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
+    voff = lane_bytes;
+  }
+  __device__ __forceinline__ f32x4 load_at(int uniform_bytes) const {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, uniform_bytes, 0));
+  }
 };
 
 // ---------------------------------------------------------------- weight fragments requested ahead
