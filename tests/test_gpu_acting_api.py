@@ -202,3 +202,30 @@ def test_vectorised_learner_tracks_the_oracle_loop():
     close(L.actor.e.get_flat(), ag.flat("actor_e"), rtol=5e-5, what="actor weights")
     close(L.critic.e.get_flat(), ag.flat("critic_e"), rtol=5e-5, what="critic weights")
     np.testing.assert_array_equal(L.actor.t.get_flat(), L.actor.e.get_flat())       # copied on calls 0 and 2
+
+
+def test_reference_training_loops_and_checkpoint_round_trip(tmp_path):
+    """`train` / `train_DDPG` (Curious_GAN.py:172-307) on the drop-in classes for two short episodes, and
+    the variables saved and restored under their TensorFlow names (Curious_GAN.py:247-251)."""
+    import rl_gan_amd as R
+    cfg = R.Settings(MAX_EP_STEPS=30, MEMORY_CAPACITY=40, BATCH_SIZE=16, SEED=1)
+    ag = R.Agent(cfg)
+    hist = R.train(ag, episodes=2, log=None)
+    assert len(hist) == 2 and all(np.isfinite(list(h.values())).all() for h in hist)
+    assert ag.M.pointer == sum(h["steps"] for h in hist) > cfg.MEMORY_CAPACITY
+    assert hist[1]["D_loss"] > 0 and hist[1]["G_loss"] > 0 and ag.var < 2.0
+    assert ag.actor.t_replace_counter == ag.M.pointer - cfg.MEMORY_CAPACITY
+    names = ag.variables()
+    assert "Actor/eval_net/l1/kernel" in names and "Discriminator/eval_net/l1/w1_G" in names and len(names) == 2 * 8 + 2 * 9 + 9 + 10
+    path = str(tmp_path / "Curious_GAN.npz")
+    ag.save_checkpoint(path)
+    other = R.Agent(R.Settings(SEED=7))
+    assert not np.array_equal(other.actor.state.e.get_flat(), ag.actor.state.e.get_flat())
+    other.load_checkpoint(path)
+    for a, b in ((other.actor.state.e, ag.actor.state.e), (other.critic.state.t, ag.critic.state.t),
+                 (other.generator.state.net, ag.generator.state.net), (other.discriminator.state.net, ag.discriminator.state.net)):
+        np.testing.assert_array_equal(a.get_flat(), b.get_flat())
+    s = np.linspace(-1, 1, 7)
+    np.testing.assert_array_equal(other.actor.choose_action(s), ag.actor.choose_action(s))     # fragment images followed
+    h2 = R.train_DDPG(R.Agent(cfg), episodes=2, log=None)
+    assert len(h2) == 2 and all(np.isfinite(h["R"]) for h in h2)
