@@ -329,8 +329,8 @@ typedef struct { uint32_t* mt_state; int64_t n_pop; int32_t n; int64_t* out_idx;
 
 /* One launch for everything that only READS the networks between two updates: the loss evaluation of
  * the update just done, the acting step that follows it, and the index draw for the next minibatch
- * (any of the three may be NULL).  Acting and evaluation tiles are dealt round-robin so that every
- * compute unit holds one of each. */
+ * (any of the three may be NULL).  With equal tile counts every compute unit holds one acting, one D-loss
+ * and one G-loss tile. */
 int rlgan_rollout_eval_rows(const rlgan_act_t* act, const rlgan_eval_t* eval, const rlgan_sample_t* sample,
                             int32_t* ticket, void* stream);
 

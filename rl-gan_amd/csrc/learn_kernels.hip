@@ -281,18 +281,29 @@ __global__ __launch_bounds__(THREADS) void gen_step_kernel(const GenArgs A) {
 constexpr int PHASE1_LDS = CRITIC_LDS > DISC_LDS ? CRITIC_LDS : DISC_LDS;
 constexpr int PHASE2_LDS = ACTOR_LDS > GEN_LDS ? ACTOR_LDS : GEN_LDS;
 
-// even workgroups walk critic tiles, odd ones discriminator tiles (both steps have the same tile count)
+// Role of a workgroup in a two-role launch: the first half of the grid walks the tiles of role 0, the
+// second half those of role 1.  Workgroups are placed breadth-first (one per compute unit before any
+// gets a second), so with one tile per compute unit and role every compute unit ends up holding one
+// tile of each role -- the same amount of work everywhere -- and the longer role starts first.
+__device__ __forceinline__ void role_of(int& role, int& tile) {
+  const int b = blockIdx.x, half = gridDim.x >> 1;
+  role = b >= half;
+  tile = role ? b - half : b;
+}
+
 __global__ __launch_bounds__(THREADS) void phase1_kernel(const CriticArgs C, const DiscArgs D) {
   __shared__ __attribute__((aligned(16))) float smem[PHASE1_LDS];
-  const int tile = blockIdx.x >> 1;
-  if (blockIdx.x & 1) disc_tile(D, smem, tile);
+  int role, tile;
+  role_of(role, tile);
+  if (role) disc_tile(D, smem, tile);
   else critic_tile(C, smem, tile);
 }
 
 __global__ __launch_bounds__(THREADS) void phase2_kernel(const ActorArgs Aa, const GenArgs G) {
   __shared__ __attribute__((aligned(16))) float smem[PHASE2_LDS];
-  const int tile = blockIdx.x >> 1;
-  if (blockIdx.x & 1) gen_tile(G, smem, tile);
+  int role, tile;
+  role_of(role, tile);
+  if (role) gen_tile(G, smem, tile);
   else actor_tile(Aa, smem, tile);
 }
 

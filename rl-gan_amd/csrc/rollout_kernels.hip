@@ -290,8 +290,8 @@ __device__ __forceinline__ void eval_finish(const EvalArgs& A) {
 }
 
 // ------------------------------------------------------------------------------------------
-// one launch: acting tiles, D-loss tiles, G-loss tiles (dealt round-robin so that every compute unit
-// holds one of each), plus one workgroup drawing the next minibatch's replay indices
+// one launch: acting tiles, D-loss tiles, G-loss tiles (one of each per compute unit when the tile counts
+// are equal), plus one workgroup drawing the next minibatch's replay indices
 // ------------------------------------------------------------------------------------------
 struct SampleArgs { uint32_t* mt_state; uint32_t rng, mask; int n; long long* out; };
 
@@ -304,19 +304,16 @@ __global__ __launch_bounds__(THREADS) void rollout_eval_kernel(const ActArgs A, 
   __shared__ int flag;
   const int b = blockIdx.x;
   const int n_roles = n_act + 2 * n_eval;
+  // ranges, longest role first: acting tiles, D-loss tiles, G-loss tiles, then the index draw.  Workgroups
+  // are placed breadth-first over the compute units, so equal tile counts give every unit one of each.
   if (b >= n_roles) {
     mt_choice_body<THREADS>(Sm.mt_state, Sm.rng, Sm.mask, Sm.n, Sm.out, (uint32_t*)smem);
-  } else if (n_act == n_eval) {
-    const int role = b % 3, tile = b / 3;
-    if (role == 0) act_tile(A, smem, tile);
-    else if (role == 1) eval_d_tile(E, smem, tile);
-    else eval_g_tile(E, smem, tile);
   } else if (b < n_act) {
     act_tile(A, smem, b);
+  } else if (b < n_act + n_eval) {
+    eval_d_tile(E, smem, b - n_act);
   } else {
-    const int e = b - n_act;
-    if (e & 1) eval_g_tile(E, smem, e >> 1);
-    else eval_d_tile(E, smem, e >> 1);
+    eval_g_tile(E, smem, b - n_act - n_eval);
   }
   if (!ticket) return;
   if (last_workgroup(ticket, gridDim.x, &flag)) {
