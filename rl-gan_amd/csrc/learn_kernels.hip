@@ -2,6 +2,7 @@
 // backward-to-inputs), the batch-reduction "weight pass" (dW = X^T dZ), gradient reduction,
 // TF-1.x RMSProp / Adam and the target-network update.  gfx950 only.
 #include "rlgan_tiles.h"
+#include <algorithm>
 
 using namespace rlgan;
 
@@ -343,7 +344,10 @@ __global__ __launch_bounds__(THREADS) void mlp_forward_kernel(const FwdArgs A) {
 // ------------------------------------------------------------------------------------------
 // weight pass: G_l[chunk] = X_l[chunk rows]^T * dZ_l[chunk rows] for every layer of up to three networks
 // ------------------------------------------------------------------------------------------
-constexpr int WD = 4;            // 16-row groups of operands kept in flight
+#ifndef RLGAN_WD
+#define RLGAN_WD 4
+#endif
+constexpr int WD = RLGAN_WD;     // steps of operands kept in flight
 constexpr int MAX_WITEMS = 12;   // 3 networks x 4 layers
 struct WItem {
   const float* X; const float* dZ; float* gout;     // gout: chunk 0 of this layer's padded gradient image
@@ -353,76 +357,86 @@ struct WItem {
 };
 struct WArgs { WItem it[MAX_WITEMS]; int n_items; };
 
-// acc[i] += X[groups g0..g1, strip]^T * dZ[groups g0..g1, tile i].  xsrc / zsrc: buffer sources whose
-// lane offset addresses this lane's float4 in group 0 (work arrays are [group][column][16 rows]: lane
-// (q, j) reads rows 4q..4q+3 of column j); xs / zs: bytes between groups.  Buffer loads keep the address
-// arithmetic on the scalar unit (vector ALU work would not overlap with the MFMAs).
-template <int T>
-__device__ __forceinline__ void wgrad_pipe(f32x4 (&acc)[T], const FragSrc& xsrc, int xs, const FragSrc& zsrc, int zs,
-                                           int g0, int g1) {
-  const int n = g1 - g0;
-  if (n <= 0) return;
-  const int nblk = (n + WD - 1) / WD;
-  const int last = g1 - 1;
+// One workgroup = one 16-row strip of dW for one batch chunk of n 16-row groups.  Column tiles
+// 0..4*(NT/4)-1 are dealt to the four waves, T = NT/4 each; a wave with such tiles walks every group of
+// the chunk.  The R = NT%4 left-over tiles are shared by rows: group g is wave (g & 3)'s, and the four
+// partial sums meet in LDS in wave order.  Inside every block of four groups a wave starts at its own
+// group ((step + wave) & 3), so that its duty falls on steps 0, 4, 8, ... and register indices stay
+// static; a wave without dealt tiles (NT < 4) visits only its own groups.  One pipeline of D steps
+// of operands in flight covers both kinds of tile: the chain of dependent memory round trips per
+// workgroup is ceil(steps / D) long.
+// xsrc / zt / zr: buffer sources whose lane offset addresses this lane's float4 in group 0 (work
+// arrays are [group][column][16 rows]: lane (q, j) reads rows 4q..4q+3 of column j); xs / zs: bytes
+// between groups.  Buffer loads keep the address arithmetic on the scalar unit (vector ALU work would
+// not overlap with the MFMAs).
+template <int T, int R, int D>
+__device__ __forceinline__ void wgrad_pipe(f32x4* acc, f32x4* accr, const FragSrc& xsrc, int xs, const FragSrc& zt,
+                                           const FragSrc& zr, int zs, int g0, int n, int wave) {
+  constexpr bool ALL = T > 0;
+  constexpr int DUTY = ALL ? 4 : 1, NR = D / DUTY;
+  static_assert(D % 4 == 0, "blocks of four groups");
+  const int nsteps = ALL ? ((n + 3) & ~3) : ((n + 3) >> 2);
+  const int nblk = (nsteps + D - 1) / D;
   const f32x4 zero{0.f, 0.f, 0.f, 0.f};
-  f32x4 a[WD], b[WD][T];
-#pragma unroll
-  for (int j = 0; j < WD; ++j) {
-    const int g = g0 + j, gc = min(g, last);
-    const f32x4 av = xsrc.load_at(gc * xs);
-    a[j] = g < g1 ? av : zero;
-#pragma unroll
-    for (int i = 0; i < T; ++i) b[j][i] = zsrc.load_at(gc * zs + i * 1024);
+  f32x4 a[D], b[D][ALL ? T : 1], br[NR][R > 0 ? R : 1];
+#define RLGAN_WFILL(j, k)                                                                        \
+  {                                                                                              \
+    const int g = ALL ? (((k) & ~3) | (((k) + wave) & 3)) : 4 * (k) + wave;                      \
+    const int gc = g0 + min(g, n - 1);                                                           \
+    const f32x4 av = xsrc.load_at(gc * xs);                                                      \
+    a[j] = g < n ? av : zero;                                                                    \
+    _Pragma("unroll") for (int i = 0; i < T; ++i) b[j][i] = zt.load_at(gc * zs + i * 1024);      \
+    if (R > 0 && (j) % DUTY == 0) {                                                              \
+      _Pragma("unroll") for (int i = 0; i < R; ++i) br[(j) / DUTY][i] = zr.load_at(gc * zs + i * 1024); \
+    }                                                                                            \
   }
+#define RLGAN_WUSE(j)                                                                            \
+  {                                                                                              \
+    _Pragma("unroll") for (int m = 0; m < 4; ++m) {                                              \
+      _Pragma("unroll") for (int i = 0; i < T; ++i)                                              \
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][m], b[j][i][m], acc[i], 0, 0, 0);     \
+      if (R > 0 && (j) % DUTY == 0) {                                                            \
+        _Pragma("unroll") for (int i = 0; i < R; ++i)                                            \
+          accr[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][m], br[(j) / DUTY][i][m], accr[i], 0, 0, 0); \
+      }                                                                                          \
+    }                                                                                            \
+  }
+#pragma unroll
+  for (int j = 0; j < D; ++j) RLGAN_WFILL(j, j)
   for (int blk = 1; blk < nblk; ++blk) {
 #pragma unroll
-    for (int j = 0; j < WD; ++j) {
-#pragma unroll
-      for (int m = 0; m < 4; ++m) {
-#pragma unroll
-        for (int i = 0; i < T; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][m], b[j][i][m], acc[i], 0, 0, 0);
-      }
-      const int g = g0 + blk * WD + j, gc = min(g, last);
-      const f32x4 av = xsrc.load_at(gc * xs);
-      a[j] = g < g1 ? av : zero;
-#pragma unroll
-      for (int i = 0; i < T; ++i) b[j][i] = zsrc.load_at(gc * zs + i * 1024);
-      __builtin_amdgcn_sched_barrier(0);   // keep the refill WD groups ahead of its use
+    for (int j = 0; j < D; ++j) {
+      RLGAN_WUSE(j)
+      RLGAN_WFILL(j, blk * D + j)
+      __builtin_amdgcn_sched_barrier(0);   // keep the refill D steps ahead of its use
     }
   }
 #pragma unroll
-  for (int j = 0; j < WD; ++j) {
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-#pragma unroll
-      for (int i = 0; i < T; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][m], b[j][i][m], acc[i], 0, 0, 0);
-    }
-  }
+  for (int j = 0; j < D; ++j) RLGAN_WUSE(j)
+#undef RLGAN_WFILL
+#undef RLGAN_WUSE
 }
 
-// One workgroup = one 16-row strip of dW for one batch chunk.  4*(NT/4) column tiles are dealt to
-// the four waves (each walks all rows of the chunk); the NT%4 left-over tiles are computed by all
-// four waves together, each taking a quarter of the rows, and summed through LDS in wave order.
 template <int NT>
 __device__ __forceinline__ void wpass_body(const WItem& it, int strip, int chunk, float* part) {
   constexpr int TPW = NT / 4, REM = NT % 4, LDP = REM * 16 + 4;
   const int lane = threadIdx.x & 63, wave = wave_id();
   const int q4 = (lane >> 4) * 4, j = lane & 15;
   const int gb = chunk * it.groups_per_chunk;
-  const int ge = min(it.n_groups, gb + it.groups_per_chunk);
+  const int n = min(it.n_groups, gb + it.groups_per_chunk) - gb;
   const int xs = it.ldx * 64, zs = it.ldz * 64;            // bytes per 16-row group
   FragSrc xsrc, zsrc_t, zsrc_r;
   xsrc.set_bytes(it.X, ((16 * strip + j) * 16 + q4) * 4);
   zsrc_t.set_bytes(it.dZ, (j * 16 + q4 + (wave * TPW) * 256) * 4);
   zsrc_r.set_bytes(it.dZ, (j * 16 + q4 + (4 * TPW) * 256) * 4);
   float* gout = it.gout + (size_t)chunk * it.gstride + (size_t)(16 * strip) * it.np;
-  if constexpr (REM > 0) {
-    const int per = (it.groups_per_chunk + 3) >> 2;
-    const int w0 = gb + wave * per, w1 = min(ge, w0 + per);
-    f32x4 accr[REM];
+  f32x4 acc[TPW > 0 ? TPW : 1], accr[REM > 0 ? REM : 1];
 #pragma unroll
-    for (int i = 0; i < REM; ++i) accr[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    wgrad_pipe<REM>(accr, xsrc, xs, zsrc_r, zs, w0, w1);
+  for (int i = 0; i < (TPW > 0 ? TPW : 1); ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < (REM > 0 ? REM : 1); ++i) accr[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  wgrad_pipe<TPW, REM, WD>(acc, accr, xsrc, xs, zsrc_t, zsrc_r, zs, gb, n, wave);
+  if constexpr (REM > 0) {
     float* pw = part + wave * ROWS * LDP + q4 * LDP + j;
 #pragma unroll
     for (int i = 0; i < REM; ++i) {
@@ -431,10 +445,6 @@ __device__ __forceinline__ void wpass_body(const WItem& it, int strip, int chunk
     }
   }
   if constexpr (TPW > 0) {
-    f32x4 acc[TPW];
-#pragma unroll
-    for (int i = 0; i < TPW; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    wgrad_pipe<TPW>(acc, xsrc, xs, zsrc_t, zs, gb, ge);
 #pragma unroll
     for (int i = 0; i < TPW; ++i) {
       const int col = 16 * (wave * TPW + i) + j;
@@ -771,9 +781,19 @@ int rlgan_weight_grads(const rlgan_wgrad_job_t* jobs, int n_jobs, int s_dim, int
       it.X = X[l]; it.dZ = Z[l]; it.gout = J.gslabs + g.goff[l];
       it.ldx = ldx[l]; it.ldz = ldz[l]; it.nstrips = g.kp[l] / 16; it.nt = g.ntf[l]; it.np = g.np[l];
       it.n_groups = J.rows / ROWS; it.groups_per_chunk = cr / ROWS; it.gstride = g.gpad_floats;
-      it.blk0 = b;
-      b += it.nstrips * (cdiv(nc, 8) * 8);          // a multiple of 8: see the XCD mapping in wpass_kernel
     }
+  }
+  // Workgroups are placed on the compute units in blockIdx order, all of them resident at once.  With
+  // the long workgroups (many column tiles x many row groups) first, each unit gets an even share of
+  // them and the short ones fill in behind.
+  std::stable_sort(A.it, A.it + A.n_items, [](const WItem& a, const WItem& c) {
+    return a.nt * a.groups_per_chunk > c.nt * c.groups_per_chunk;
+  });
+  for (int i = 0; i < A.n_items; ++i) {
+    WItem& it = A.it[i];
+    it.blk0 = b;
+    const int nc = cdiv(it.n_groups, it.groups_per_chunk);
+    b += it.nstrips * (cdiv(nc, 8) * 8);            // a multiple of 8: see the XCD mapping in wpass_kernel
   }
   hipLaunchKernelGGL(wpass_kernel, dim3(b), dim3(THREADS), 0, (hipStream_t)stream, A);
   return launched();
