@@ -64,8 +64,9 @@ typedef struct {
 
 /* per-network activation / pre-activation-gradient work arrays written by a *_rows kernel and
  * consumed by rlgan_weight_grads.  `rows` rows (a multiple of 16) of `ld` columns each, stored as
- * [rows/16][ld][16]: column-major inside every 16-row tile.  ld = 32 for x0, 208 for
- * h1/h2/dz1/dz2, geom.ld3 for h3/dz3, 16 for dz4.  All device. */
+ * [rows/16][4][ld][4]: inside every 16-row tile, four blocks of four rows, each block holding for
+ * every column its four rows (element (r, c) of a tile at (r/4)*4*ld + 4*c + r%4).  ld = 32 for x0,
+ * 208 for h1/h2/dz1/dz2, geom.ld3 for h3/dz3, 16 for dz4.  All device. */
 typedef struct {
   float* x0;  float* h1;  float* h2;  float* h3;
   float* dz1; float* dz2; float* dz3; float* dz4;

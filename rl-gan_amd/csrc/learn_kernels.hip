@@ -365,9 +365,9 @@ struct WArgs { WItem it[MAX_WITEMS]; int n_items; };
 // static; a wave without dealt tiles (NT < 4) visits only its own groups.  One pipeline of D steps
 // of operands in flight covers both kinds of tile: the chain of dependent memory round trips per
 // workgroup is ceil(steps / D) long.
-// xsrc / zt / zr: buffer sources whose lane offset addresses this lane's float4 in group 0 (work
-// arrays are [group][column][16 rows]: lane (q, j) reads rows 4q..4q+3 of column j); xs / zs: bytes
-// between groups.  Buffer loads keep the address arithmetic on the scalar unit (vector ALU work would
+// xsrc / zt / zr: buffer sources whose lane offset addresses this lane's float4 in group 0 (lane
+// (q, j) reads rows 4q..4q+3 of column j, see work_off; the next column tile is 256 bytes on); xs / zs:
+// bytes between groups.  Buffer loads keep the address arithmetic on the scalar unit (vector ALU work would
 // not overlap with the MFMAs).
 template <int T, int R, int D>
 __device__ __forceinline__ void wgrad_pipe(f32x4* acc, f32x4* accr, const FragSrc& xsrc, int xs, const FragSrc& zt,
@@ -377,21 +377,19 @@ __device__ __forceinline__ void wgrad_pipe(f32x4* acc, f32x4* accr, const FragSr
   static_assert(D % 4 == 0, "blocks of four groups");
   const int nsteps = ALL ? ((n + 3) & ~3) : ((n + 3) >> 2);
   const int nblk = (nsteps + D - 1) / D;
-  const f32x4 zero{0.f, 0.f, 0.f, 0.f};
   f32x4 a[D], b[D][ALL ? T : 1], br[NR][R > 0 ? R : 1];
 #define RLGAN_WFILL(j, k)                                                                        \
   {                                                                                              \
     const int g = ALL ? (((k) & ~3) | (((k) + wave) & 3)) : 4 * (k) + wave;                      \
     const int gc = g0 + min(g, n - 1);                                                           \
-    const f32x4 av = xsrc.load_at(gc * xs);                                                      \
-    a[j] = g < n ? av : zero;                                                                    \
-    _Pragma("unroll") for (int i = 0; i < T; ++i) b[j][i] = zt.load_at(gc * zs + i * 1024);      \
+    a[j] = xsrc.load_at(gc * xs);                                                                \
+    _Pragma("unroll") for (int i = 0; i < T; ++i) b[j][i] = zt.load_at(gc * zs + i * 256);      \
     if (R > 0 && (j) % DUTY == 0) {                                                              \
-      _Pragma("unroll") for (int i = 0; i < R; ++i) br[(j) / DUTY][i] = zr.load_at(gc * zs + i * 1024); \
+      _Pragma("unroll") for (int i = 0; i < R; ++i) br[(j) / DUTY][i] = zr.load_at(gc * zs + i * 256); \
     }                                                                                            \
   }
-#define RLGAN_WUSE(j)                                                                            \
-  {                                                                                              \
+#define RLGAN_WUSE(j, k)                                                                         \
+  if ((ALL ? (((k) & ~3) | (((k) + wave) & 3)) : 4 * (k) + wave) < n) {                          \
     _Pragma("unroll") for (int m = 0; m < 4; ++m) {                                              \
       _Pragma("unroll") for (int i = 0; i < T; ++i)                                              \
         acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][m], b[j][i][m], acc[i], 0, 0, 0);     \
@@ -406,13 +404,13 @@ __device__ __forceinline__ void wgrad_pipe(f32x4* acc, f32x4* accr, const FragSr
   for (int blk = 1; blk < nblk; ++blk) {
 #pragma unroll
     for (int j = 0; j < D; ++j) {
-      RLGAN_WUSE(j)
+      RLGAN_WUSE(j, (blk - 1) * D + j)
       RLGAN_WFILL(j, blk * D + j)
       __builtin_amdgcn_sched_barrier(0);   // keep the refill D steps ahead of its use
     }
   }
 #pragma unroll
-  for (int j = 0; j < D; ++j) RLGAN_WUSE(j)
+  for (int j = 0; j < D; ++j) RLGAN_WUSE(j, (nblk - 1) * D + j)
 #undef RLGAN_WFILL
 #undef RLGAN_WUSE
 }
@@ -426,9 +424,9 @@ __device__ __forceinline__ void wpass_body(const WItem& it, int strip, int chunk
   const int n = min(it.n_groups, gb + it.groups_per_chunk) - gb;
   const int xs = it.ldx * 64, zs = it.ldz * 64;            // bytes per 16-row group
   FragSrc xsrc, zsrc_t, zsrc_r;
-  xsrc.set_bytes(it.X, ((16 * strip + j) * 16 + q4) * 4);
-  zsrc_t.set_bytes(it.dZ, (j * 16 + q4 + (wave * TPW) * 256) * 4);
-  zsrc_r.set_bytes(it.dZ, (j * 16 + q4 + (4 * TPW) * 256) * 4);
+  xsrc.set_bytes(it.X, work_off(it.ldx, q4, 16 * strip + j) * 4);
+  zsrc_t.set_bytes(it.dZ, work_off(it.ldz, q4, 16 * (wave * TPW) + j) * 4);
+  zsrc_r.set_bytes(it.dZ, work_off(it.ldz, q4, 16 * (4 * TPW) + j) * 4);
   float* gout = it.gout + (size_t)chunk * it.gstride + (size_t)(16 * strip) * it.np;
   f32x4 acc[TPW > 0 ? TPW : 1], accr[REM > 0 ? REM : 1];
 #pragma unroll

@@ -84,6 +84,14 @@ __host__ __device__ inline int wf_offset(const Geo& g, int l, int k, int n) { re
 // float offset of W[k][n] of layer l in the backward-fragment image (operand element (row n, col k))
 __host__ __device__ inline int wb_offset(const Geo& g, int l, int k, int n) { return g.offb[l] + frag_offset(g.ntb[l], n, k); }
 
+// Work arrays (activations and their gradients kept for the weight-gradient kernel) hold the batch in
+// tiles of 16 rows; inside a tile of `ld` columns the order is [4 blocks of 4 rows][ld columns][4 rows].
+// An MFMA lane (q = lane / 16, j = lane % 16) needs rows 4q..4q+3 of column 16*t + j: one 16-byte
+// access, and the sixteen lanes of a q touch 256 consecutive bytes.  (With the columns outermost,
+// [ld columns][16 rows], the same lanes touch sixteen different 64-byte pieces and the load unit
+// needs almost twice as long per instruction.)
+__host__ __device__ inline int work_off(int ld, int r, int c) { return (r >> 2) * (ld * 4) + c * 4 + (r & 3); }
+
 #ifdef __HIPCC__
 // ---------------------------------------------------------------- activations
 template <int ACT> __device__ __forceinline__ float act_f(float z) {
@@ -271,7 +279,7 @@ __device__ __forceinline__ void dense_tiles(Pre<NT, NG>& p, const float* xq, int
     f32x4 v;
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[r] = f(r0 + r, col, z[r], hv[i][r]);
-    if (gdst) *(f32x4*)(gdst + col * 16 + r0) = v;
+    if (gdst) *(f32x4*)(gdst + work_off(NT * 16, r0, col)) = v;
   }
 }
 
@@ -301,7 +309,7 @@ __device__ __forceinline__ void rega_tiles(Pre<NT, 1>& p, const f32x4 a, int r0,
     f32x4 v;
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[r] = f(r0 + r, col, acc[i][r], hv[i][r]);
-    if (gdst) *(f32x4*)(gdst + col * 16 + r0) = v;
+    if (gdst) *(f32x4*)(gdst + work_off(NT * 16, r0, col)) = v;
   }
 }
 template <int NT, class P, class F, class X>
@@ -379,8 +387,8 @@ __device__ __forceinline__ float chain_sum1(const float* part, int row, int col)
 //   pre   pre(row, col): a value the epilogue needs per output element (read before the MFMAs so its
 //         LDS latency hides behind them); NoPre when none is needed
 //   f     f(row, col, z, pre_value) -> value: the epilogue, once per output element (it writes LDS)
-//   gdst  when non-null, the returned values are also stored to this tile of a global work array laid
-//         out [column][16 rows] (one 16-byte store per lane and column)
+//   gdst  when non-null, the returned values are also stored to this tile of a global work array of
+//         NT*16 columns (see work_off; one 16-byte store per lane and column)
 //   next  called by every wave between its last MFMA and its epilogue: the place to issue() the next
 //         layer's Pre
 //   chain / ys, ldy: optional chained one-tile layer (see Chain); ys is the LDS tile f writes
@@ -441,9 +449,8 @@ struct Tiles {
   float* part; // PART_FLOATS: partial sums of chained layers
 };
 
-// global work arrays of one network, already offset to this 16-row tile (or all null).  Inside a
-// tile every array is laid out [column][16 rows], so that the weight-gradient kernel reads the
-// four batch rows an MFMA lane needs with one 16-byte load.
+// global work arrays of one network, already offset to this 16-row tile (or all null); layout inside
+// a tile: work_off
 struct ActsG {
   float* x0; float* h1; float* h2; float* h3; float* dz1; float* dz2; float* dz3; float* dz4;
 };
@@ -496,7 +503,7 @@ __device__ __forceinline__ void net_forward(const float* __restrict__ wf, const 
       *(f32x4*)(h3 + row * L3 + k0) = v;
       if (STORE) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) ws.h3[(k0 + r) * 16 + row] = v[r];
+        for (int r = 0; r < 4; ++r) ws.h3[work_off(16, row, k0 + r)] = v[r];
       }
       f32x4 acc{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -542,7 +549,7 @@ __device__ __forceinline__ void net_backward(const float* __restrict__ wb, const
   const int r0 = (lane >> 4) * 4, c0 = lane & 15;
   if (STORE) {
     const int r = threadIdx.x >> 4, c = threadIdx.x & 15;
-    ws.dz4[c * 16 + r] = t.out[r * LD_O + c];
+    ws.dz4[work_off(16, r, c)] = t.out[r * LD_O + c];
   }
   const int n3 = g.N3;
   Pre<NT_H, NT3> p3;
@@ -566,7 +573,7 @@ __device__ __forceinline__ void net_backward(const float* __restrict__ wb, const
     for (int r = 0; r < 4; ++r) dz3[r] = r0 + r < n3 ? d[r] * act_d<N::A3>(hv[r]) : 0.f;
     if (STORE && wave_id() == 0) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) ws.dz3[(r0 + r) * 16 + c0] = dz3[r];
+      for (int r = 0; r < 4; ++r) ws.dz3[work_off(16, c0, r0 + r)] = dz3[r];
     }
     // dz2 tiles of this wave: one k-group, its A operand is dz3 in registers
     dense16_rega(p3, dz3, g2, f2, STORE ? ws.dz2 : nullptr, [&] { p2.issue(wb + g.offb[1]); });
@@ -623,7 +630,7 @@ __device__ __forceinline__ void load_x0(float* x0, int row0, int n_rows, MatIn b
     }
     if (c == k0) v = 1.f;
     x0[r * LD_X0 + c] = v;
-    if (x0_global) x0_global[c * 16 + r] = v;        // work arrays are [column][16 rows] per tile
+    if (x0_global) x0_global[work_off(X0_COLS, r, c)] = v;
   }
 }
 

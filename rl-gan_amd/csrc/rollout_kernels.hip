@@ -215,11 +215,12 @@ struct EvalArgs {
 };
 constexpr int EVAL_LDS = PART_FLOATS + SET_FLOATS + 64;
 
-// input tile from a global x0 work array tile ([column][16 rows], as load_x0 mirrors it)
+// input tile from a global x0 work array tile (as load_x0 mirrors it, layout: work_off), read in
+// memory order
 __device__ __forceinline__ void load_x0_tile(float* x0, const float* __restrict__ g) {
   for (int e = threadIdx.x; e < ROWS * X0_COLS; e += THREADS) {
-    const int r = e & 15, c = e >> 4;
-    x0[r * LD_X0 + c] = g[c * 16 + r];
+    const int r = 4 * (e / (4 * X0_COLS)) + (e & 3), c = (e >> 2) % X0_COLS;
+    x0[r * LD_X0 + c] = g[e];
   }
 }
 
