@@ -290,17 +290,25 @@ class StepEngine:
         return _lib.Eval(self.s_dim, self.a_dim, n, G.net.net(), D.net.net(), mat(s), mat(g_data), mat(a), mat(s_),
                          1.0 - smooth, self._inv_gb(n), lp.data_ptr(), out.data_ptr(), ptr(idx), None, None)
 
-    def eval_args_after_update(self, G: AdamState, D: AdamState, n: int, smooth: float = 0.0) -> _lib.Eval:
+    def eval_args_after_update(self, G: AdamState, D: AdamState, n: int, smooth: float = 0.0,
+                               totals: bool = True) -> _lib.Eval:
         """Evaluation of the minibatch the last `update` of `n` rows ran on, read from the input tiles
-        its D and G steps left in the work arrays (no gather, the replay ring is not touched)."""
+        its D and G steps left in the work arrays (no gather, the replay ring is not touched).
+        With totals=False the launch only leaves the per-tile sums; `eval_totals(n)` adds them up later."""
         R = rows16(n)
         lp = self.loss_parts("e", 2 * (R // 16))
-        out = self.losses[self.LOSS_D_EVAL:self.LOSS_D_EVAL + 2]
+        out = self.losses[self.LOSS_D_EVAL:self.LOSS_D_EVAL + 2] if totals else None
         wd, wg = self.workspace("d", D.net, 2 * R), self.workspace("g", G.net, R)
         none = mat(None)
         return _lib.Eval(self.s_dim, self.a_dim, n, G.net.net(), D.net.net(), none, none, none, none,
-                         1.0 - smooth, self._inv_gb(n), lp.data_ptr(), out.data_ptr(), None,
+                         1.0 - smooth, self._inv_gb(n), lp.data_ptr(), ptr(out), None,
                          wd.x0.data_ptr(), wg.x0.data_ptr())
+
+    def eval_totals(self, n: int) -> None:
+        """D_loss and G_loss from the per-tile sums an evaluation of `n` rows left (same order of
+        additions as the in-launch totals)."""
+        nt = rows16(n) // 16
+        sum_parts(self.loss_parts("e", 2 * nt), nt, 2, self._inv_gb(n), self.losses[self.LOSS_D_EVAL:self.LOSS_D_EVAL + 2])
 
     def gan_eval(self, G: AdamState, D: AdamState, g_data, s_, s, a, smooth: float = 0.0, idx=None):
         """D_loss and G_loss of this rank's shard, divided by the global batch (summing over ranks gives

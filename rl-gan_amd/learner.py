@@ -84,6 +84,7 @@ class CuriousLearner:
         self.t = 0           # vector steps taken (host mirror of ctr[1])
         self.updates = 0
         self._graph = None
+        self._eval_pending = False
         self.reset_all()
 
     # ---- environment side ---------------------------------------------------------------------
@@ -136,8 +137,10 @@ class CuriousLearner:
 
     def _tail_body(self) -> None:
         """Everything between two updates that only reads the networks, as one launch: D_loss / G_loss of
-        the update just done (Curious_GAN.py:212-213), the next acting step and the next index draw."""
-        ev = self.engine.eval_args_after_update(self.gen, self.disc, self.cfg.batch_size, self.cfg.smooth)
+        the update just done (Curious_GAN.py:212-213) as per-tile sums (`losses()` adds them up when
+        asked: a total inside the launch would have one workgroup wait for all the others), the next
+        acting step and the next index draw."""
+        ev = self.engine.eval_args_after_update(self.gen, self.disc, self.cfg.batch_size, self.cfg.smooth, totals=False)
         act, sample, ticket = self._act_args(), self._sample_args(), self.engine.ticket().data_ptr()
         self.engine._timed("rollout_eval_rows", lambda: check(
             lib.rlgan_rollout_eval_rows(act, ev, sample, ticket, _stream()), "rlgan_rollout_eval_rows"))
@@ -148,6 +151,7 @@ class CuriousLearner:
         self._update_body()
         s, s_, g, a = self._ring_fields()
         self.engine.gan_eval(self.gen, self.disc, g, s_, s, a, self.cfg.smooth, self.idx)
+        self._eval_pending = False
         self.updates += 1
 
     def capture(self) -> None:
@@ -183,6 +187,7 @@ class CuriousLearner:
         else:
             self._update_body()
             self._tail_body()
+        self._eval_pending = True
         self.memory.pointer += self.cfg.n_env
         self.t += 1
         self.updates += 1
@@ -196,6 +201,9 @@ class CuriousLearner:
     def losses(self) -> dict:
         """Losses of the last update as global-batch means.  Each rank holds its shard's sums divided
         by the global batch, so with more than one rank this is a collective: call it on every rank."""
+        if self._eval_pending:
+            self.engine.eval_totals(self.cfg.batch_size)
+            self._eval_pending = False
         l = self.engine.losses.clone()
         self.exchange.all_reduce_sum(l)
         l = l.cpu().numpy()
