@@ -306,7 +306,13 @@ int rlgan_philox_uniform(double* out, int n_pairs, uint64_t seed, uint32_t strea
  *  var     : device float64 scalar.  When var_decay > 0 the last workgroup sets
  *            var = max(var*var_decay, var_min) if the pointer after this step exceeds `capacity`
  *            (`if M.pointer > MEMORY_CAPACITY`, Curious_GAN.py:197-198).
- * `ticket` (see rlgan_gan_eval_rows) is required when counters is non-NULL or var_decay > 0. */
+ *  counters_out / var_out: when counters_out is non-NULL the launch leaves `counters` and `var` as it
+ *            read them and writes the advanced values (and the decayed or unchanged noise scale, var_out
+ *            required when var is given) to these other buffers instead; the caller swaps the two pairs
+ *            between launches (a captured loop holds two graphs, one per direction).  Nothing then waits
+ *            for the last workgroup.
+ * `ticket` (see rlgan_gan_eval_rows) is required when counters_out is NULL and counters is non-NULL or
+ * var_decay > 0. */
 typedef struct {
   int32_t s_dim, a_dim, n_env;
   rlgan_net_t actor_eval, gen, disc;
@@ -322,6 +328,7 @@ typedef struct {
   uint64_t rng_seed;
   int32_t* ep_t; int32_t max_ep_steps, mode_hard; const double* reset_u; int32_t* n_resets;
   double var_decay, var_min;
+  int64_t* counters_out; double* var_out;
 } rlgan_act_t;
 int rlgan_act_rows(const rlgan_act_t* act, int32_t* ticket, void* stream);
 

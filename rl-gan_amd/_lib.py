@@ -81,7 +81,7 @@ class Act(C.Structure):
                 ("pointer", C.c_int64), ("step", C.c_int64), ("counters", _fp),
                 ("reward_out", _fp), ("done_out", _fp), ("rng_seed", C.c_uint64),
                 ("ep_t", _fp), ("max_ep_steps", _i32), ("mode_hard", _i32), ("reset_u", _fp), ("n_resets", _fp),
-                ("var_decay", C.c_double), ("var_min", C.c_double)]
+                ("var_decay", C.c_double), ("var_min", C.c_double), ("counters_out", _fp), ("var_out", _fp)]
 
 
 class Conv(C.Structure):

@@ -79,6 +79,7 @@ struct ActArgs {
   unsigned long long rng_seed;  // != 0: draw noise (when `noise` is null) and reset uniforms (when `reset_u` is null) in the kernel
   int32_t* ep_t; int max_ep_steps, mode_hard; const double* reset_u; int32_t* n_resets;   // episode cut (ep_t null: none)
   double var_decay, var_min;  // var <- max(var*var_decay, var_min) once the ring is full (var_decay <= 0: never)
+  long long* counters_out; double* var_out;   // when set: advanced values go here (written by tile 0), inputs stay
 };
 
 constexpr int ACT_LDS = PART_FLOATS + SET_FLOATS + 5 * ROWS * 16 + 2 * ROWS * 2;
@@ -116,6 +117,12 @@ __device__ __forceinline__ void act_tile(const ActArgs& A, float* smem, int tile
     }
   }
   const double var = A.var ? A.var[0] : 0.0;
+  if (A.counters_out && tile == 0 && threadIdx.x == 0) {
+    // nothing in this launch reads the output pair, so no workgroup has to wait for the others
+    const long long p = ptr0 + A.n_env;
+    A.counters_out[0] = p; A.counters_out[1] = step + 1;
+    if (A.var_out) A.var_out[0] = (A.var_decay > 0.0 && p > A.capacity) ? fmax(var * A.var_decay, A.var_min) : var;
+  }
   __syncthreads();
   load_x0(t.x0, row0, A.n_env, lin(sbuf, 16, S), nil(), nil(), nullptr);
   __syncthreads();
@@ -193,7 +200,7 @@ __device__ __forceinline__ void act_tile(const ActArgs& A, float* smem, int tile
 // noise scale once learning has started (`if M.pointer > MEMORY_CAPACITY: var = max(var*.9999, VAR_MIN)`,
 // Curious_GAN.py:197-198)
 __device__ __forceinline__ void act_finish(const ActArgs& A) {
-  if (threadIdx.x != 0) return;
+  if (threadIdx.x != 0 || A.counters_out) return;
   long long p = A.pointer + A.n_env;
   if (A.counters) { p = A.counters[0] + A.n_env; A.counters[0] = p; A.counters[1] += 1; }
   if (A.var && A.var_decay > 0.0 && p > A.capacity) A.var[0] = fmax(A.var[0] * A.var_decay, A.var_min);
@@ -303,11 +310,15 @@ __global__ __launch_bounds__(THREADS) void rollout_eval_kernel(const ActArgs A, 
                                                                int n_act, int n_eval, int32_t* ticket) {
   __shared__ __attribute__((aligned(16))) float smem[ROLLOUT_LDS];
   __shared__ int flag;
-  const int b = blockIdx.x;
-  const int n_roles = n_act + 2 * n_eval;
-  // ranges, longest role first: acting tiles, D-loss tiles, G-loss tiles, then the index draw.  Workgroups
-  // are placed breadth-first over the compute units, so equal tile counts give every unit one of each.
-  if (b >= n_roles) {
+  // The index draw is one workgroup's serial chain (about 13 us alone for 4096 indices): it goes first
+  // and at raised priority, because the youngest waves of a compute unit get the issue slots the older
+  // ones leave, and behind three MFMA-bound tiles the chain would end well after them.  Then ranges,
+  // longest role first: acting tiles, D-loss tiles, G-loss tiles.  Workgroups are placed breadth-first
+  // over the compute units, so equal tile counts give every unit one of each.
+  const int n_draw = Sm.mt_state ? 1 : 0;
+  const int b = (int)blockIdx.x - n_draw;
+  if (b < 0) {
+    __builtin_amdgcn_s_setprio(3);
     mt_choice_body<THREADS>(Sm.mt_state, Sm.rng, Sm.mask, Sm.n, Sm.out, (uint32_t*)smem);
   } else if (b < n_act) {
     act_tile(A, smem, b);
@@ -342,6 +353,10 @@ int make_act_args(ActArgs& A, const rlgan_act_t* a) {
   A.reward_out = a->reward_out; A.done_out = a->done_out; A.rng_seed = a->rng_seed;
   A.ep_t = a->ep_t; A.max_ep_steps = a->max_ep_steps; A.mode_hard = a->mode_hard; A.reset_u = a->reset_u; A.n_resets = a->n_resets;
   A.var_decay = a->var_decay; A.var_min = a->var_min;
+  if (a->counters_out && (!a->counters || a->counters_out == a->counters)) return RLGAN_E_ARG;
+  if (a->counters_out && a->var && (!a->var_out || a->var_out == a->var)) return RLGAN_E_ARG;
+  if (!a->counters_out && a->var_out) return RLGAN_E_ARG;
+  A.counters_out = (long long*)a->counters_out; A.var_out = a->var_out;
   return 0;
 }
 
@@ -377,7 +392,7 @@ int launch_rollout(const rlgan_act_t* act, const rlgan_eval_t* eval, const rlgan
   if (eval) { if (const int rc = make_eval_args(E, eval)) return rc; n_eval = E.n_tiles; }
   if (const int rc = make_sample_args(Sm, sample)) return rc;
   // the last-workgroup step is needed for the counters, the noise-scale decay and the loss totals
-  const bool need_ticket = (act && (act->counters || act->var_decay > 0.0)) || (eval && eval->loss_out);
+  const bool need_ticket = (act && !act->counters_out && (act->counters || act->var_decay > 0.0)) || (eval && eval->loss_out);
   if (need_ticket && !ticket) return RLGAN_E_ARG;
   const int grid = n_act + 2 * n_eval + (Sm.mt_state ? 1 : 0);
   if (grid <= 0) return RLGAN_E_ARG;

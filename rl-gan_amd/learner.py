@@ -76,14 +76,18 @@ class CuriousLearner:
         self.ep_t = torch.zeros(cfg.n_env, dtype=torch.int32, device=dev)
         self.n_resets = torch.zeros(1, dtype=torch.int32, device=dev)
         self.memory = DeviceMemory(cfg.memory_capacity, 3 * S + A + 2, rng=MT19937Device(cfg.seed + 7919 * rank))
-        self.var = torch.full((1,), cfg.var_init, dtype=torch.float64, device=dev)
+        # Per-step scalars the acting launch reads and advances live in two copies: a launch reads copy
+        # `_cur` and writes the advanced values to the other one, so no workgroup has to wait for the rest
+        # of the launch before it may overwrite them.
+        self._var2 = torch.full((2, 1), cfg.var_init, dtype=torch.float64, device=dev)     # noise scale
+        self._ctr2 = torch.zeros((2, 2), dtype=torch.int64, device=dev)                    # replay pointer, vector steps
+        self._cur = 0
         self.u = torch.zeros((cfg.n_env, 2), dtype=torch.float64, device=dev)
         self.idx = torch.zeros(cfg.batch_size, dtype=torch.int64, device=dev)
         self.philox_seed = ((cfg.seed << 20) ^ (rank + 1)) or 1
-        self.ctr = torch.zeros(2, dtype=torch.int64, device=dev)   # device counters: replay pointer, vector steps
         self.t = 0           # vector steps taken (host mirror of ctr[1])
         self.updates = 0
-        self._graph = None
+        self._graph = None   # after capture(): the two graphs of an iteration, indexed by `_cur`
         self._eval_pending = False
         self.reset_all()
 
@@ -94,17 +98,29 @@ class CuriousLearner:
         self.env.reset(self.u)
         self.ep_t.zero_()
 
-    def _act_args(self, noise: Optional[torch.Tensor] = None) -> _lib.Act:
+    @property
+    def var(self) -> torch.Tensor:
+        """Exploration noise scale (device float64 [1]), Curious_GAN.py:173,198."""
+        return self._var2[self._cur]
+
+    @property
+    def ctr(self) -> torch.Tensor:
+        """Device counters (int64 [2]): replay pointer, vector steps."""
+        return self._ctr2[self._cur]
+
+    def _act_args(self, noise: Optional[torch.Tensor] = None, cur: Optional[int] = None) -> _lib.Act:
         """The acting step of every environment with its bookkeeping: noise and goal draws (Philox, keyed
         by the device step counter), replay store, episode cut, counters, noise-scale decay.  Every
         per-step scalar is read from device memory, so the same launch can be replayed in a graph."""
         cfg, m = self.cfg, self.memory
+        cur = self._cur if cur is None else cur
         return _lib.Act(cfg.s_dim, cfg.a_dim, cfg.n_env, self.actor.e.net(), self.gen.net.net(), self.disc.net.net(),
                         self.env.handle(), self.env.state32.data_ptr(), noise.data_ptr() if noise is not None else None,
-                        self.var.data_ptr(), cfg.ita, m._data.data_ptr(), m.capacity, m.dims, m.ld, 0, 0,
-                        self.ctr.data_ptr(), self.env.reward.data_ptr(), self.env.done.data_ptr(), self.philox_seed,
+                        self._var2[cur].data_ptr(), cfg.ita, m._data.data_ptr(), m.capacity, m.dims, m.ld, 0, 0,
+                        self._ctr2[cur].data_ptr(), self.env.reward.data_ptr(), self.env.done.data_ptr(), self.philox_seed,
                         self.ep_t.data_ptr(), cfg.max_ep_steps, 1 if cfg.mode == 'hard' else 0, None,
-                        self.n_resets.data_ptr(), cfg.var_decay, cfg.var_min)
+                        self.n_resets.data_ptr(), cfg.var_decay, cfg.var_min,
+                        self._ctr2[cur ^ 1].data_ptr(), self._var2[cur ^ 1].data_ptr())
 
     def _sample_args(self) -> _lib.Sample:
         m = self.memory
@@ -121,8 +137,8 @@ class CuriousLearner:
         full = self.memory.pointer + self.cfg.n_env > self.memory.capacity
         act = self._act_args(noise)
         sample = self._sample_args() if full else None
-        check(lib.rlgan_rollout_eval_rows(act, None, sample, self.engine.ticket().data_ptr(), _stream()),
-              "rlgan_rollout_eval_rows")
+        check(lib.rlgan_rollout_eval_rows(act, None, sample, None, _stream()), "rlgan_rollout_eval_rows")
+        self._cur ^= 1
         self.memory.pointer += self.cfg.n_env      # host mirror of ctr[0]
         self.t += 1                                # host mirror of ctr[1]
 
@@ -135,15 +151,15 @@ class CuriousLearner:
         self.engine.update(self.actor, self.critic, self.gen, self.disc, self.memory._data, self.cfg.smooth,
                            with_eval=False, idx=self.idx)
 
-    def _tail_body(self) -> None:
+    def _tail_body(self, cur: Optional[int] = None) -> None:
         """Everything between two updates that only reads the networks, as one launch: D_loss / G_loss of
         the update just done (Curious_GAN.py:212-213) as per-tile sums (`losses()` adds them up when
         asked: a total inside the launch would have one workgroup wait for all the others), the next
         acting step and the next index draw."""
         ev = self.engine.eval_args_after_update(self.gen, self.disc, self.cfg.batch_size, self.cfg.smooth, totals=False)
-        act, sample, ticket = self._act_args(), self._sample_args(), self.engine.ticket().data_ptr()
+        act, sample = self._act_args(cur=cur), self._sample_args()
         self.engine._timed("rollout_eval_rows", lambda: check(
-            lib.rlgan_rollout_eval_rows(act, ev, sample, ticket, _stream()), "rlgan_rollout_eval_rows"))
+            lib.rlgan_rollout_eval_rows(act, ev, sample, None, _stream()), "rlgan_rollout_eval_rows"))
 
     def update(self) -> None:
         """One minibatch update with its two losses (Curious_GAN.py:199-213), without acting.
@@ -155,8 +171,8 @@ class CuriousLearner:
         self.updates += 1
 
     def capture(self) -> None:
-        """Record one full iteration (update, then losses + next acting step) as a HIP graph; `step()`
-        then replays it.  Needs a full replay ring.  Two eager iterations run first so every work
+        """Record one full iteration (update, then losses + next acting step) as HIP graphs; `step()`
+        then replays them.  Needs a full replay ring.  Two eager iterations run first so every work
         array exists."""
         assert self.ready(), "fill() the replay ring before capture()"
         assert self.engine.kernel_events is None
@@ -168,11 +184,14 @@ class CuriousLearner:
                 self.step()
         cur.wait_stream(s)
         torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            self._update_body()
-            self._tail_body()
-        self._graph = g
+        graphs = [None, None]
+        for cur in (self._cur, self._cur ^ 1):       # one graph per direction of the counter hand-over
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._update_body()
+                self._tail_body(cur)
+            graphs[cur] = g
+        self._graph = graphs
 
     def step(self) -> None:
         """One iteration of the training loop.  While the ring fills: an acting step.  Afterwards: the
@@ -183,10 +202,11 @@ class CuriousLearner:
             self.rollout_step()
             return
         if self._graph is not None:
-            self._graph.replay()
+            self._graph[self._cur].replay()
         else:
             self._update_body()
             self._tail_body()
+        self._cur ^= 1
         self._eval_pending = True
         self.memory.pointer += self.cfg.n_env
         self.t += 1
