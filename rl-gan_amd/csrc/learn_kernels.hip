@@ -21,7 +21,7 @@ struct CriticArgs {
   float* loss_parts;
   int32_t* counter;           // optional: += 1 per launch (t_replace_counter, DDPG.py:64,178)
 };
-constexpr int CRITIC_LDS = PART_FLOATS + SET_FLOATS + O_FLOATS + 64;
+constexpr int CRITIC_LDS = PART_FLOATS + SET_FLOATS + O_FLOATS + 64 + STAGE_FLOATS;
 
 __device__ __forceinline__ void critic_tile(const CriticArgs& A, float* smem, int tile) {
   if (tile == 0 && threadIdx.x == 0 && A.counter) A.counter[0] += 1;   // nothing in this launch reads it
@@ -29,30 +29,33 @@ __device__ __forceinline__ void critic_tile(const CriticArgs& A, float* smem, in
   TileSet ts = carve_set(smem + PART_FLOATS);
   float* dsave = smem + PART_FLOATS + SET_FLOATS;   // [16][LD_O]
   float* small = dsave + O_FLOATS;                  // y[16], dq[16], scratch[16]
+  float* stage = small + 64;                        // [16][STAGE_LD]: s | a | r | s' of the tile's rows
   const Tiles t = mk(ts, part);
   const int row0 = tile * ROWS;
   const int S = A.gc.S, Ad = A.gc.A;
   const ActsG none{};
+  const float* st_s = stage; const float* st_a = stage + S; const float* st_r = stage + S + Ad; const float* st_sn = stage + S + Ad + 1;
 
   // target action a' = actor_target(s')
   Pre<NT_H, 2> p_at; p_at.issue(A.actor_t.wf + A.ga.offf[0]);
-  load_x0(t.x0, row0, A.n_rows, gin(A.s_next, S), nil(), nil(), nullptr);
+  stage_rows(stage, row0, A.n_rows, gin(A.s, S), gin(A.a, Ad), gin(A.r, 1), gin(A.s_next, S));
+  __syncthreads();
+  load_x0(t.x0, row0, A.n_rows, lin(st_sn, STAGE_LD, S), nil(), nil(), nullptr);
   __syncthreads();
   Pre<NT_H, 2> p_ct;
   net_forward<NET_ACTOR, false>(A.actor_t.wf, A.ga, t, none, p_at, [&] { p_ct.issue(A.critic_t.wf + A.gc.offf[0]); });
   // q' = critic_target(s', a')
-  load_x0(t.x0, row0, A.n_rows, gin(A.s_next, S), lin(t.out, LD_O, Ad), nil(), nullptr);
+  load_x0(t.x0, row0, A.n_rows, lin(st_sn, STAGE_LD, S), lin(t.out, LD_O, Ad), nil(), nullptr);
   __syncthreads();
   Pre<NT_H, 2> p_ce;
   net_forward<NET_CRITIC, false>(A.critic_t.wf, A.gc, t, none, p_ct, [&] { p_ce.issue(A.critic_e.wf + A.gc.offf[0]); });
   if (threadIdx.x < ROWS) {
-    const int gr = row0 + threadIdx.x;
-    const float rew = gr < A.n_rows ? mat_at(A.r, gr, 0) : 0.f;
+    const float rew = st_r[threadIdx.x * STAGE_LD];                        // 0 beyond n_rows
     small[threadIdx.x] = rew + A.gamma * t.out[threadIdx.x * LD_O];      // y = R + gamma*q'  DDPG.py:142
   }
   // q = critic_eval(s, a)
   const ActsG wc = acts_at(A.acts_c.p, row0, A.gc.ld3);
-  load_x0(t.x0, row0, A.n_rows, gin(A.s, S), gin(A.a, Ad), nil(), wc.x0);
+  load_x0(t.x0, row0, A.n_rows, lin(st_s, STAGE_LD, S), lin(st_a, STAGE_LD, Ad), nil(), wc.x0);
   __syncthreads();
   PreAll<1> p_cb;
   net_forward<NET_CRITIC, true>(A.critic_e.wf, A.gc, t, wc, p_ce, [&] { p_cb.issue(A.critic_e.wb + A.gc.offb[3]); });
@@ -76,14 +79,14 @@ __device__ __forceinline__ void critic_tile(const CriticArgs& A, float* smem, in
       const int gr = row0 + r;
       float v = 0.f;
       if (c < Ad && gr < A.n_rows) {
-        const float af = mat_at(A.a, gr, c);
+        const float af = st_a[r * STAGE_LD + c];
         v = t.x0[r * LD_X0 + S + c] * (1.f - af * af);
       }
       dsave[r * LD_O + c] = v;
     }
     __syncthreads();
     const ActsG wa = acts_at(A.acts_a.p, row0, A.ga.ld3);
-    load_x0(t.x0, row0, A.n_rows, gin(A.s, S), nil(), nil(), wa.x0);
+    load_x0(t.x0, row0, A.n_rows, lin(st_s, STAGE_LD, S), nil(), nil(), wa.x0);
     __syncthreads();
     PreAll<1> p_ab;
     net_forward<NET_ACTOR, true>(A.actor_e.wf, A.ga, t, wa, p_ae, [&] { p_ab.issue(A.actor_e.wb + A.ga.offb[3]); });
@@ -132,7 +135,7 @@ __device__ __forceinline__ void actor_tile(const ActorArgs& A, float* smem, int 
   __syncthreads();
   Pre<NT_H, 2> p_c;
   net_forward<NET_ACTOR, true>(A.actor_e.wf, A.ga, ta, wa, p_a, [&] { p_c.issue(A.critic_e.wf + A.gc.offf[0]); });   // a = actor_eval(s), live
-  load_x0(tc.x0, row0, A.n_rows, gin(A.s, S), lin(ta.out, LD_O, Ad), nil(), nullptr);
+  load_x0(tc.x0, row0, A.n_rows, lin(ta.x0, LD_X0, S), lin(ta.out, LD_O, Ad), nil(), nullptr);   // s: from the actor's input tile
   __syncthreads();
   PreAll<1> p_cb;
   net_forward<NET_CRITIC, false>(A.critic_e.wf, A.gc, tc, none, p_c, [&] { p_cb.issue(A.critic_e.wb + A.gc.offb[3]); });
@@ -174,7 +177,7 @@ struct DiscArgs {
   float* loss_parts;
   int32_t* counter;           // optional: += 1 per launch (the optimizer's step count)
 };
-constexpr int DISC_LDS = PART_FLOATS + SET_FLOATS + 64;
+constexpr int DISC_LDS = PART_FLOATS + SET_FLOATS + 64 + STAGE_FLOATS;
 
 __device__ __forceinline__ void disc_tile(const DiscArgs& A, float* smem, int tile) {
   if (tile == 0 && threadIdx.x == 0 && A.counter) A.counter[0] += 1;   // nothing in this launch reads it
@@ -184,12 +187,16 @@ __device__ __forceinline__ void disc_tile(const DiscArgs& A, float* smem, int ti
   const Tiles t = mk(ts, part);
   const int row0 = tile * ROWS;
   const int S = A.gd.S, Ad = A.gd.A;
+  float* stage = small + 64;                        // [16][STAGE_LD]: s | g | a | s' of the tile's rows
   float ltot = 0.f;
   Pre<NT_H, 2> p_f; p_f.issue(A.disc.wf + A.gd.offf[0]);
+  stage_rows(stage, row0, A.n_rows, gin(A.s, S), gin(A.g, S), gin(A.a, Ad), gin(A.s_next, S));
+  __syncthreads();
 #pragma unroll 1
   for (int pass = 0; pass < 2; ++pass) {
     const ActsG wd = acts_at(A.acts_d.p, pass * A.rows16 + row0, A.gd.ld3);
-    load_x0(t.x0, row0, A.n_rows, gin(A.s, S), gin(pass == 0 ? A.g : A.s_next, S), gin(A.a, Ad), wd.x0);
+    load_x0(t.x0, row0, A.n_rows, lin(stage, STAGE_LD, S), lin(stage + (pass == 0 ? S : 2 * S + Ad), STAGE_LD, S),
+            lin(stage + 2 * S, STAGE_LD, Ad), wd.x0);
     __syncthreads();
     PreAll<1> p_b;
     net_forward<NET_DISC, true>(A.disc.wf, A.gd, t, wd, p_f, [&] { p_b.issue(A.disc.wb + A.gd.offb[3]); });
@@ -246,7 +253,7 @@ __device__ __forceinline__ void gen_tile(const GenArgs& A, float* smem, int tile
   __syncthreads();
   Pre<NT_H, 2> p_d;
   net_forward<NET_GEN, true>(A.gen.wf, A.gg, tg, wg, p_g, [&] { p_d.issue(A.disc.wf + A.gd.offf[0]); });   // g^ = G(s, a), live
-  load_x0(td.x0, row0, A.n_rows, gin(A.s, S), lin(tg.out, LD_O, S), gin(A.a, Ad), nullptr);
+  load_x0(td.x0, row0, A.n_rows, lin(tg.x0, LD_X0, S), lin(tg.out, LD_O, S), lin(tg.x0 + S, LD_X0, Ad), nullptr);   // s, a: from G's input tile
   __syncthreads();
   PreAll<1> p_db;
   net_forward<NET_DISC, false>(A.disc.wf, A.gd, td, none, p_d, [&] { p_db.issue(A.disc.wb + A.gd.offb[3]); });

@@ -19,6 +19,27 @@ __device__ __forceinline__ float mat_at(const Mat& m, int gr, int c) {
   return m.p[row * m.ld + c];
 }
 
+// The minibatch fields a tile works on, fetched once: up to four column blocks side by side in an LDS
+// tile [16][STAGE_LD], zeros for rows at or beyond n_rows.  A tile that runs several network passes on
+// the same rows reads them from here (lin(stage + column, STAGE_LD, width)) instead of paying a chain of
+// two global round trips (row index, then row) at the start of every pass.  No barrier inside.
+constexpr int STAGE_LD = 32, STAGE_FLOATS = ROWS * STAGE_LD;
+__device__ __forceinline__ void stage_rows(float* stage, int row0, int n_rows, MatIn b0, MatIn b1, MatIn b2, MatIn b3) {
+  const int e0 = b0.w, e1 = e0 + b1.w, e2 = e1 + b2.w, e3 = e2 + b3.w;
+  for (int e = threadIdx.x; e < STAGE_FLOATS; e += THREADS) {
+    const int r = e / STAGE_LD, c = e % STAGE_LD;
+    const int gr = row0 + r;
+    float v = 0.f;
+    if (gr < n_rows && c < e3) {
+      if (c < e0) v = matin_at(b0, gr, r, c);
+      else if (c < e1) v = matin_at(b1, gr, r, c - e0);
+      else if (c < e2) v = matin_at(b2, gr, r, c - e1);
+      else v = matin_at(b3, gr, r, c - e2);
+    }
+    stage[e] = v;
+  }
+}
+
 struct TileSet { float* x0; float* h1; float* h2; float* h3; float* out; };
 __device__ __forceinline__ Tiles mk(const TileSet& s, float* part) { return Tiles{s.x0, s.h1, s.h2, s.h3, s.out, part}; }
 constexpr int SET_FLOATS = X0_FLOATS + 2 * WIDE_FLOATS + T3_FLOATS + O_FLOATS;
