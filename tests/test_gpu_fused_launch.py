@@ -40,17 +40,20 @@ def _rollout_fixture(n, cap, seed):
 
 def test_in_kernel_draws_and_episode_cut_equal_the_separate_kernels():
     """(a) noise and reset uniforms produced by rlgan_philox_* and fed in, episode cut by
-    rlgan_env_autoreset; (b) everything inside rlgan_act_rows.  Same ring, states and counters."""
+    rlgan_env_autoreset; (b) everything inside rlgan_act_rows, counters advanced in place by the last
+    workgroup; (c) the same with counters and noise scale handed over between two copies (no ticket).
+    Same ring, states and counters."""
     from rl_gan_amd import _lib
     from rl_gan_amd.core import _stream
     lib, check = _lib.lib, _lib.check
     n, cap, seed, steps, max_ep = 100, 256, 77, 7, 3
     out = []
-    for fused in (False, True):
+    for fused in (False, True, "handover"):
         p, env, mem = _rollout_fixture(n, cap, 4)
-        var = torch.tensor([2.0], dtype=torch.float64, device="cuda")
+        var2 = torch.full((2, 1), 2.0, dtype=torch.float64, device="cuda")
+        ctr2 = torch.zeros((2, 2), dtype=torch.int64, device="cuda")
+        var, ctr = var2[0], ctr2[0]
         ep_t = torch.zeros(n, dtype=torch.int32, device="cuda")
-        ctr = torch.zeros(2, dtype=torch.int64, device="cuda")
         ticket = torch.zeros(1, dtype=torch.int32, device="cuda")
         nres = torch.zeros(1, dtype=torch.int32, device="cuda")
         z = torch.zeros((n, 2), dtype=torch.float32, device="cuda")
@@ -58,7 +61,14 @@ def test_in_kernel_draws_and_episode_cut_equal_the_separate_kernels():
         for t in range(steps):
             common = (7, 2, n, p.A.e.net(), p.G.net.net(), p.D.net.net(), env.handle(), env.state32.data_ptr())
             ring = (mem._data.data_ptr(), cap, 25, mem.ld)
-            if fused:
+            if fused == "handover":
+                cur = t & 1
+                act = _lib.Act(*common, None, var2[cur].data_ptr(), 0.01, *ring, 0, 0, ctr2[cur].data_ptr(), env.reward.data_ptr(),
+                               env.done.data_ptr(), seed, ep_t.data_ptr(), max_ep, 1, None, nres.data_ptr(), 0.9, 0.1,
+                               ctr2[cur ^ 1].data_ptr(), var2[cur ^ 1].data_ptr())
+                check(lib.rlgan_act_rows(act, None, _stream()))
+                var, ctr = var2[cur ^ 1], ctr2[cur ^ 1]
+            elif fused:
                 act = _lib.Act(*common, None, var.data_ptr(), 0.01, *ring, 0, 0, ctr.data_ptr(), env.reward.data_ptr(),
                                env.done.data_ptr(), seed, ep_t.data_ptr(), max_ep, 1, None, nres.data_ptr(), 0.9, 0.1)
                 check(lib.rlgan_act_rows(act, ticket.data_ptr(), _stream()))
@@ -76,12 +86,14 @@ def test_in_kernel_draws_and_episode_cut_equal_the_separate_kernels():
         assert int(ticket.item()) == 0
         out.append(dict(ring=mem._data.cpu().numpy(), state=env.state32.cpu().numpy(), goal=env.goal.cpu().numpy(),
                         ep_t=ep_t.cpu().numpy(), ctr=ctr.tolist(), nres=int(nres.item()), var=float(var.item())))
-    a, b = out
-    assert a["ctr"] == b["ctr"] == [steps * n, steps]
-    assert a["nres"] == b["nres"] and a["nres"] >= 2 * n          # max_ep = 3: everyone was cut at least twice
-    for k in ("ring", "state", "goal", "ep_t"):
-        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
-    assert abs(a["var"] - b["var"]) < 1e-15 and abs(b["var"] - 2.0 * 0.9 ** 5) < 1e-12   # steps 2..6 end beyond the ring size
+    a = out[0]
+    for b in out[1:]:
+        assert a["ctr"] == b["ctr"] == [steps * n, steps]
+        assert a["nres"] == b["nres"] and a["nres"] >= 2 * n          # max_ep = 3: everyone was cut at least twice
+        for k in ("ring", "state", "goal", "ep_t"):
+            np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+        assert abs(a["var"] - b["var"]) < 1e-15 and abs(b["var"] - 2.0 * 0.9 ** 5) < 1e-12   # steps 2..6 end beyond the ring size
+    assert out[1]["var"] == out[2]["var"]
 
 
 def test_one_launch_of_losses_acting_and_draw_equals_three_calls():
