@@ -95,3 +95,18 @@ def encoder_backward(dy, params, layers, caches):
         dy, dw, db = conv_backward(dy, w, cache, k, s)
         grads.append((dw, db))
     return dy, grads[::-1]
+
+
+def dense_forward(x, w, b, act=True):
+    """The 256-unit head after the flattened features (`tf.layers.dense(s, 256, activation=tf.nn.elu)`
+    Conv_model.py:24; `dense1` then `tf.nn.elu` Conv_model.py:52-56).  w: [K, N]; returns (y, cache)."""
+    z = x @ w + b
+    y = elu(z) if act else z
+    return y, (x, y)
+
+
+def dense_backward(dy, w, cache, act=True):
+    """Returns (dx, dw, db)."""
+    x, y = cache
+    dz = dy * np.where(y > 0, 1.0, y + 1.0) if act else dy         # ELU' from the output
+    return dz @ w.T, x.T @ dz, dz.sum(0)

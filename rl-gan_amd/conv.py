@@ -86,12 +86,75 @@ class ConvLayer:
         return dx
 
 
+class DenseLayer:
+    """The fully connected head of the encoders, `tf.layers.dense(features, 256, activation=tf.nn.elu)`
+    (Conv_model.py:24 `fc`; Conv_model.py:52-56 `dense1` + elu).  Parameters in canonical order: the
+    [K, N] kernel, then the bias row."""
+
+    def __init__(self, k: int, n: int = 256, rng: Optional[np.random.RandomState] = None, bias_init: float = 0.0,
+                 kernel: Optional[np.ndarray] = None, bias: Optional[np.ndarray] = None):
+        assert k % 4 == 0 and n % 4 == 0, "16-byte rows"
+        self.k, self.n, self.n_params = k, n, (k + 1) * n
+        if kernel is None:
+            rng = rng or np.random.RandomState()
+            lim = np.sqrt(6.0 / (k + n))                                          # tf.layers.dense default: glorot uniform
+            kernel = rng.uniform(-lim, lim, (k, n))
+            bias = np.full(n, bias_init)
+        flat = np.concatenate([np.asarray(kernel, np.float32).ravel(), np.asarray(bias, np.float32).ravel()])
+        assert flat.size == self.n_params
+        self.canon = torch.from_numpy(flat).to(device())
+        self.grad = torch.zeros(self.n_params, dtype=torch.float32, device=device())
+        self._scratch: Optional[torch.Tensor] = None
+
+    def _slabs(self, m_out: int, k_red: int):
+        """(scratch, count) for a product with an m_out x n result summed over k_red terms."""
+        ns = lib.rlgan_dense_slabs(m_out, self.n, k_red)
+        if ns <= 1:
+            return None, 1
+        need = ns * m_out * self.n
+        if self._scratch is None or self._scratch.numel() < need:
+            self._scratch = torch.empty(need, dtype=torch.float32, device=device())
+        return self._scratch, ns
+
+    def kernel_bias(self) -> Tuple[np.ndarray, np.ndarray]:
+        f = self.canon.cpu().numpy()
+        return f[:self.k * self.n].reshape(self.k, self.n), f[self.k * self.n:]
+
+    def forward(self, x: torch.Tensor, act: bool = True) -> torch.Tensor:
+        assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.ndim == 2 and x.shape[1] == self.k
+        y = torch.empty((x.shape[0], self.n), dtype=torch.float32, device=x.device)
+        sc, ns = self._slabs(x.shape[0], self.k + 1)
+        check(lib.rlgan_dense_forward(x.data_ptr(), self.k, self.canon.data_ptr(), y.data_ptr(), self.n, x.shape[0], self.k, self.n,
+                                      1 if act else 0, None if sc is None else sc.data_ptr(), ns, _stream()), "rlgan_dense_forward")
+        return y
+
+    def backward(self, x: torch.Tensor, y: torch.Tensor, dy: torch.Tensor, need_dx: bool = True, act: bool = True):
+        """Gradients of this layer: fills self.grad (kernel then bias), returns dx or None."""
+        m = x.shape[0]
+        dz = dy
+        if act:
+            dz = torch.empty_like(dy)
+            check(lib.rlgan_elu_backward(dy.data_ptr(), y.data_ptr(), dz.data_ptr(), dy.numel(), _stream()), "rlgan_elu_backward")
+        sc, ns = self._slabs(self.k + 1, m)
+        check(lib.rlgan_dense_backward_weights(x.data_ptr(), self.k, dz.data_ptr(), self.n, self.grad.data_ptr(), m, self.k, self.n,
+                                               None if sc is None else sc.data_ptr(), ns, _stream()), "rlgan_dense_backward_weights")
+        if not need_dx:
+            return None
+        dx = torch.empty_like(x)
+        check(lib.rlgan_dense_backward_input(dz.data_ptr(), self.n, self.canon.data_ptr(), dx.data_ptr(), self.k, m, self.k, self.n,
+                                             _stream()), "rlgan_dense_backward_input")
+        return dx
+
+
 class ConvEncoder:
     """A stack of ConvLayers on [n, h, w, c] frames; output flattened to [n, features] like the
     reference's `tf.reshape(s, [-1, prod(shape[1:])])` (Conv_model.py:23,51)."""
 
     def __init__(self, h: int, w: int, c_in: int, layers: Sequence[Tuple[int, int, int]] = DOOM_HEAD,
-                 rng: Optional[np.random.RandomState] = None, bias_init: float = 0.0, params=None):
+                 rng: Optional[np.random.RandomState] = None, bias_init: float = 0.0, params=None,
+                 dense: int = 0, dense_params=None):
+        """dense > 0 appends the `dense`-unit ELU head (256 in the reference); its parameters are drawn
+        after the convolutions' from the same stream, or given as (kernel, bias)."""
         self.layers: List[ConvLayer] = []
         rng = rng or np.random.RandomState()
         for i, (f, k, s) in enumerate(layers):
@@ -99,18 +162,30 @@ class ConvEncoder:
             L = ConvLayer(h, w, c_in, f, k, s, rng=rng, bias_init=bias_init, **kw)
             self.layers.append(L)
             h, w, c_in = L.h_out, L.w_out, f
-        self.features = h * w * c_in
+        self.conv_features = h * w * c_in
+        self.head: Optional[DenseLayer] = None
+        if dense:
+            kw = {} if dense_params is None else {"kernel": dense_params[0], "bias": dense_params[1]}
+            self.head = DenseLayer(self.conv_features, dense, rng=rng, bias_init=bias_init, **kw)
+        self.features = dense or self.conv_features
         self._acts: List[torch.Tensor] = []
+        self._flat = self._out = None
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         self._acts = [x]
         for L in self.layers:
             x = L.forward(x)
             self._acts.append(x)
-        return x.reshape(x.shape[0], -1)
+        flat = x.reshape(x.shape[0], -1)
+        if self.head is None:
+            return flat
+        self._flat, self._out = flat, self.head.forward(flat)
+        return self._out
 
     def backward(self, dfeat: torch.Tensor, need_dx: bool = False) -> Optional[torch.Tensor]:
         """Backpropagates d(loss)/d(features) through the stack; every layer's .grad is filled."""
+        if self.head is not None:
+            dfeat = self.head.backward(self._flat, self._out, dfeat.contiguous())
         dy = dfeat.reshape(self._acts[-1].shape).contiguous()
         for i in range(len(self.layers) - 1, -1, -1):
             dy = self.layers[i].backward(self._acts[i], self._acts[i + 1], dy, need_dx=need_dx or i > 0)

@@ -1,0 +1,239 @@
+// Fully connected head of the pixel encoders: y = elu([x 1] * [W ; b]) and its two gradients
+// (`tf.layers.dense(s, 256, activation=tf.nn.elu, name='fc')` Conv_model.py:24; `dense1` + elu
+// Conv_model.py:52-56).  One LDS-tiled fp32 GEMM on v_mfma_f32_16x16x4_f32 serves all three products;
+// they differ in which operand dimension is contiguous in memory and in where the constant 1 of the
+// bias sits:
+//   forward   Y[M, N]   = [X 1][M, K+1] * Wb[K+1, N]         A k-contiguous (+ ones column),  B n-contiguous
+//   input     dX[M, K]  = dZ[M, N] * Wb[0:K, :]^T             A k-contiguous,                  B k-contiguous
+//   weights   dWb[K+1,N] = [X 1]^T[K+1, M] * dZ[M, N]         A m-contiguous (+ ones row),     B n-contiguous
+// Wb is the canonical parameter block, the [K, N] kernel followed by the bias row.  gfx950 only.
+#include "rlgan_device.h"
+#include "rlgan_host.h"
+#include <algorithm>
+#include <cstdint>
+
+using namespace rlgan;
+
+namespace {
+
+constexpr int BM = 64, BN = 64, BK = 32;   // workgroup tile of C and the reduction step
+constexpr int LDT = BK + 4;                 // LDS row: 36 floats, the 16 rows of an MFMA lane group fall on disjoint banks
+constexpr int TILE_FLOATS = 64 * LDT;
+
+struct GemmArgs {
+  const float* a; const float* b; float* c;
+  int lda, ldb, ldc;
+  int M, N, K;          // C is M x N; K = reduction length (a ones index included)
+  int a_x, a_k;         // extents of A in memory along its non-reduction / reduction dimension
+  int b_x, b_k;         // the same for B
+  int ones_x, ones_k;   // A reads as 1 at this non-reduction (reduction) index; -1: none
+  int act;              // epilogue: 1 = ELU
+  int k_split;          // reduction indices per blockIdx.y (a multiple of BK); with more than one split the
+  size_t slab;          // raw partial products go to c + blockIdx.y * slab and split_sum_kernel finishes
+};
+
+// One operand tile, 64 (x: rows of A / columns of B) by BK (k), as two float4 per thread.
+//   KCONT: memory is [x][k], a float4 holds four consecutive k of one x
+//   else:  memory is [k][x], a float4 holds four consecutive x of one k
+// Out-of-range elements read as 0, the ones index as 1 (operand A only: pass -1 otherwise).
+template <bool KCONT>
+__device__ __forceinline__ void tile_load(f32x4 (&r)[2], const float* __restrict__ p, int ld, int x0, int k0, int nx, int nk,
+                                          int ones_x, int ones_k) {
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int u = threadIdx.x + 256 * h;
+    int x, k;
+    if (KCONT) { x = x0 + (u >> 3); k = k0 + (u & 7) * 4; }
+    else       { k = k0 + (u >> 4); x = x0 + (u & 15) * 4; }
+    f32x4 v{0.f, 0.f, 0.f, 0.f};
+    if (KCONT) {
+      if (x < nx && k + 3 < nk) v = *(const f32x4*)(p + (size_t)x * ld + k);
+      else if (x < nx) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) if (k + i < nk) v[i] = p[(size_t)x * ld + k + i];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) if (k + i == ones_k || x == ones_x) v[i] = 1.f;
+    } else {
+      if (k < nk && x + 3 < nx) v = *(const f32x4*)(p + (size_t)k * ld + x);
+      else if (k < nk) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) if (x + i < nx) v[i] = p[(size_t)k * ld + x + i];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) if (x + i == ones_x || k == ones_k) v[i] = 1.f;
+    }
+    r[h] = v;
+  }
+}
+// the registers of tile_load into an LDS tile [64 x][LDT], k contiguous
+template <bool KCONT>
+__device__ __forceinline__ void tile_store(float* t, const f32x4 (&r)[2]) {
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int u = threadIdx.x + 256 * h;
+    if (KCONT) {
+      *(f32x4*)(t + (u >> 3) * LDT + (u & 7) * 4) = r[h];
+    } else {
+      const int k = u >> 4, x = (u & 15) * 4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) t[(x + i) * LDT + k] = r[h][i];
+    }
+  }
+}
+
+// C tile of one workgroup: four waves, 32 x 32 each (2 x 2 MFMA tiles); the next reduction step's
+// operands travel global -> registers while the current one is multiplied out of LDS.
+template <bool A_KCONT, bool B_KCONT>
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) float lds[4 * TILE_FLOATS];   // A and B tiles, two stages
+  // consecutive workgroups share the A tile (same rows, neighbouring column tiles)
+  const int ntn = cdiv(g.N, BN);
+  const int m0 = ((int)blockIdx.x / ntn) * BM, n0 = ((int)blockIdx.x % ntn) * BN;
+  const int lane = threadIdx.x & 63, wave = wave_id();
+  const int q4 = (lane >> 4) * 4, j = lane & 15;
+  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+  const int ax = g.a_x, ak = g.a_k;
+  f32x4 ra[2], rb[2];
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) acc[s][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const int kb = (int)blockIdx.y * g.k_split;                       // this split's reduction range
+  const int nkt = cdiv(min(g.K - kb, g.k_split), BK);
+  float* cz = g.c + (size_t)blockIdx.y * g.slab;
+  tile_load<A_KCONT>(ra, g.a, g.lda, m0, kb, ax, ak, g.ones_x, g.ones_k);
+  tile_load<B_KCONT>(rb, g.b, g.ldb, n0, kb, g.b_x, g.b_k, -1, -1);
+  tile_store<A_KCONT>(lds, ra);
+  tile_store<B_KCONT>(lds + TILE_FLOATS, rb);
+  __syncthreads();
+  for (int kt = 0; kt < nkt; ++kt) {
+    const float* as = lds + (kt & 1) * 2 * TILE_FLOATS;
+    const float* bs = as + TILE_FLOATS;
+    if (kt + 1 < nkt) {
+      tile_load<A_KCONT>(ra, g.a, g.lda, m0, kb + (kt + 1) * BK, ax, ak, g.ones_x, g.ones_k);
+      tile_load<B_KCONT>(rb, g.b, g.ldb, n0, kb + (kt + 1) * BK, g.b_x, g.b_k, -1, -1);
+    }
+#pragma unroll
+    for (int kg = 0; kg < BK / 16; ++kg) {
+      f32x4 a[2], b[2];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        a[s] = *(const f32x4*)(as + (wm + 16 * s + j) * LDT + 16 * kg + q4);
+        b[s] = *(const f32x4*)(bs + (wn + 16 * s + j) * LDT + 16 * kg + q4);
+      }
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+#pragma unroll
+          for (int t = 0; t < 2; ++t) acc[s][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][m], b[t][m], acc[s][t], 0, 0, 0);
+        }
+      }
+    }
+    if (kt + 1 < nkt) {
+      float* an = lds + ((kt + 1) & 1) * 2 * TILE_FLOATS;
+      tile_store<A_KCONT>(an, ra);
+      tile_store<B_KCONT>(an + TILE_FLOATS, rb);
+    }
+    __syncthreads();
+  }
+  // lane (q, j) of an accumulator tile holds rows 4q..4q+3 of column j
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int col = n0 + wn + 16 * t + j;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wm + 16 * s + q4 + r;
+        if (row < g.M && col < g.N) {
+          float v = acc[s][t][r];
+          if (g.act == 1) v = v > 0.f ? v : expm1f(v);
+          cz[(size_t)row * g.ldc + col] = v;
+        }
+      }
+    }
+  }
+}
+
+// c[row][col] = act(slab 0 + slab 1 + ...), slabs dense [M][N], added in slab order
+__global__ __launch_bounds__(256) void split_sum_kernel(const float* __restrict__ slabs, int n_slabs, size_t slab, int M, int N,
+                                                        float* __restrict__ c, int ldc, int act) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)M * N) return;
+  float v = 0.f;
+  for (int z = 0; z < n_slabs; ++z) v += slabs[z * slab + i];
+  if (act == 1) v = v > 0.f ? v : expm1f(v);
+  c[(i / N) * ldc + i % N] = v;
+}
+
+bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+inline int launched() { return (int)hipGetLastError(); }
+
+// The reduction is cut into n_slabs ranges when the C tiles alone would leave the chip idle or a
+// workgroup alone on its compute unit with nothing to cover its loads: partial products to `slabs`
+// ([n_slabs][M][N]), then one pass adds them in order and applies the activation.
+template <bool A_KCONT, bool B_KCONT>
+int launch_gemm(GemmArgs g, float* slabs, int n_slabs, void* stream) {
+  if (!g.a || !g.b || !g.c || g.M <= 0 || g.N <= 0 || g.K <= 0 || n_slabs < 0 || n_slabs > 256 || (n_slabs > 1 && !slabs))
+    return RLGAN_E_ARG;
+  // float4 loads: 16-byte aligned bases and leading dimensions that are multiples of four
+  if (!aligned16(g.a) || !aligned16(g.b) || (g.lda & 3) || (g.ldb & 3)) return RLGAN_E_ALIGN;
+  const long long blocks = (long long)cdiv(g.M, BM) * cdiv(g.N, BN);
+  if (blocks > 0x7fffffffll) return RLGAN_E_ARG;
+  g.k_split = g.K; g.slab = 0;
+  int nz = 1;
+  if (n_slabs > 1) {
+    g.k_split = BK * cdiv(cdiv(g.K, n_slabs), BK);
+    nz = cdiv(g.K, g.k_split);
+  }
+  if (nz == 1) {
+    hipLaunchKernelGGL((gemm_kernel<A_KCONT, B_KCONT>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g);
+    return launched();
+  }
+  float* out = g.c; const int ldc = g.ldc, act = g.act;
+  g.c = slabs; g.ldc = g.N; g.act = 0; g.slab = (size_t)g.M * g.N;
+  hipLaunchKernelGGL((gemm_kernel<A_KCONT, B_KCONT>), dim3((unsigned)blocks, nz), dim3(256), 0, (hipStream_t)stream, g);
+  hipLaunchKernelGGL(split_sum_kernel, dim3((unsigned)cdiv((long long)g.M * g.N, 256)), dim3(256), 0, (hipStream_t)stream,
+                     slabs, nz, g.slab, g.M, g.N, out, ldc, act);
+  return launched();
+}
+
+}  // namespace
+
+extern "C" {
+
+int rlgan_dense_slabs(int m_out, int n_out, int k_red) {
+  if (m_out <= 0 || n_out <= 0 || k_red <= 0) return RLGAN_E_ARG;
+  const long long tiles = (long long)cdiv(m_out, BM) * cdiv(n_out, BN);
+  const int by_chip = (int)std::min<long long>(256, cdiv(1024, tiles));       // about four workgroups per compute unit
+  const int by_work = std::max(1, k_red / (4 * BK));                          // at least four reduction steps each
+  return std::max(1, std::min(by_chip, by_work));
+}
+
+int rlgan_dense_forward(const float* x, int ldx, const float* wb, float* y, int ldy, int m, int k, int n, int act,
+                        float* slabs, int n_slabs, void* stream) {
+  if (ldx < k || ldy < n || act < 0 || act > 1) return RLGAN_E_ARG;
+  GemmArgs g{x, wb, y, ldx, n, ldy, m, n, k + 1, /*a_x*/ m, /*a_k*/ k, /*b_x*/ n, /*b_k*/ k + 1, /*ones_x*/ -1, /*ones_k*/ k, act, 0, 0};
+  return launch_gemm<true, false>(g, slabs, n_slabs, stream);
+}
+
+int rlgan_dense_backward_input(const float* dz, int lddz, const float* wb, float* dx, int lddx, int m, int k, int n, void* stream) {
+  if (lddz < n || lddx < k) return RLGAN_E_ARG;
+  // B[kk = hidden unit][x = input feature] = Wb[x][kk]: rows of Wb are the x, kk is contiguous
+  GemmArgs g{dz, wb, dx, lddz, n, lddx, m, k, n, m, n, /*b_x*/ k, /*b_k*/ n, -1, -1, 0, 0, 0};
+  return launch_gemm<true, true>(g, nullptr, 1, stream);
+}
+
+int rlgan_dense_backward_weights(const float* x, int ldx, const float* dz, int lddz, float* gwb, int m, int k, int n,
+                                 float* slabs, int n_slabs, void* stream) {
+  if (ldx < k || lddz < n) return RLGAN_E_ARG;
+  // A[row of dWb = input feature or the ones row][kk = batch row] = x[kk][feature]
+  GemmArgs g{x, dz, gwb, ldx, lddz, n, k + 1, n, m, /*a_x*/ k, /*a_k*/ m, /*b_x*/ n, /*b_k*/ m, /*ones_x*/ k, /*ones_k*/ -1, 0, 0, 0};
+  return launch_gemm<false, false>(g, slabs, n_slabs, stream);
+}
+
+}  // extern "C"

@@ -44,3 +44,69 @@ def test_conv_argument_errors():
     assert _lib.lib.rlgan_conv_geometry(_lib.Conv(84, 84, 4, 128, 3, 2), C.byref(g)) == -2    # more than four column tiles
     assert _lib.lib.rlgan_conv_geometry(_lib.Conv(84, 84, 4, 8, 5, 4), C.byref(g)) == 0
     assert (g.h_out, g.w_out, g.k_len, g.n_params) == (20, 20, 100, 808)
+
+
+@pytest.mark.parametrize("m,k,n", [(37, 64, 256), (130, 2592, 256), (64, 12800, 256), (5, 20, 12)])
+def test_dense_head_forward_and_backward(m, k, n):
+    """The 256-unit ELU head (Conv_model.py:24, :52-56) on 64 (doom), 2,592 (42x42 universe) and 12,800
+    (84x84 universe, two layers) features, ragged batch sizes, plus a shape smaller than one tile."""
+    import rl_gan_amd as R
+    from gpu_util import close
+    from oracle import conv as oc
+    rng = np.random.RandomState(m + k)
+    f32 = lambda a: a.astype(np.float32).astype(np.float64)
+    x = f32(rng.standard_normal((m, k)))
+    w = f32(rng.uniform(-1, 1, (k, n)) * np.sqrt(6.0 / (k + n)))
+    b = f32(rng.uniform(-0.1, 0.1, n))
+    y, cache = oc.dense_forward(x, w, b)
+    dy = f32(rng.standard_normal(y.shape))
+    dx, dw, db = oc.dense_backward(dy, w, cache)
+    L = R.DenseLayer(k, n, kernel=w, bias=b)
+    xt = torch.from_numpy(x.astype(np.float32)).cuda()
+    yt = L.forward(xt)
+    close(yt.cpu().numpy(), y, what="dense y")
+    dxt = L.backward(xt, yt, torch.from_numpy(dy.astype(np.float32)).cuda())
+    close(dxt.cpu().numpy(), dx, what="dense dx")
+    g = L.grad.cpu().numpy()
+    close(g[:k * n].reshape(k, n), dw, what="dense dW")
+    close(g[k * n:], db, what="dense db")
+    zt = L.forward(xt, act=False)
+    close(zt.cpu().numpy(), x @ w + b, what="dense linear")
+
+
+def test_encoder_with_dense_head_end_to_end():
+    """doom head + fc(256): features, and the gradient reaching the first conv layer."""
+    import rl_gan_amd as R
+    from gpu_util import close
+    from oracle import conv as oc
+    rng = np.random.RandomState(11)
+    f32 = lambda a: a.astype(np.float32).astype(np.float64)
+    n = 6
+    x = f32(rng.uniform(0, 1, (n, 84, 84, 4)))
+    params = [(f32(w), f32(b)) for w, b in oc.init_encoder(rng, oc.DOOM_HEAD, 4, bias=0.001)]
+    wd, bd = f32(rng.uniform(-1, 1, (64, 256)) * np.sqrt(6.0 / 320)), f32(np.full(256, 0.001))
+    feat, caches = oc.encoder_forward(x, params, oc.DOOM_HEAD)
+    y, dc = oc.dense_forward(feat.reshape(n, -1), wd, bd)
+    dy = f32(rng.standard_normal(y.shape))
+    dfeat, dw, db = oc.dense_backward(dy, wd, dc)
+    _, grads = oc.encoder_backward(dfeat.reshape(feat.shape), params, oc.DOOM_HEAD, caches)
+    enc = R.ConvEncoder(84, 84, 4, oc.DOOM_HEAD, params=params, dense=256, dense_params=(wd, bd))
+    out = enc.forward(torch.from_numpy(x.astype(np.float32)).cuda())
+    assert out.shape == (n, 256) and enc.features == 256 and enc.conv_features == 64
+    close(out.cpu().numpy(), y, what="fc output")
+    enc.backward(torch.from_numpy(dy.astype(np.float32)).cuda())
+    close(enc.head.grad.cpu().numpy()[:64 * 256].reshape(64, 256), dw, what="fc dW")
+    g0 = enc.layers[0].grad.cpu().numpy()
+    close(g0[:grads[0][0].size].reshape(grads[0][0].shape), grads[0][0], what="conv l1 dW through the head")
+
+
+def test_dense_argument_errors():
+    from rl_gan_amd import _lib
+    x = torch.zeros(8, 20, device="cuda"); wb = torch.zeros(21 * 12, device="cuda"); y = torch.zeros(8, 12, device="cuda")
+    f = _lib.lib.rlgan_dense_forward
+    assert f(x.data_ptr(), 20, wb.data_ptr(), y.data_ptr(), 12, 8, 20, 12, 1, None, 1, None) == 0
+    assert f(x.data_ptr(), 18, wb.data_ptr(), y.data_ptr(), 12, 8, 20, 12, 1, None, 1, None) == -1      # ldx < k
+    assert f(x.data_ptr(), 22, wb.data_ptr(), y.data_ptr(), 12, 8, 20, 12, 1, None, 1, None) == -5      # ldx not a multiple of 4
+    assert f(x.data_ptr() + 4, 20, wb.data_ptr(), y.data_ptr(), 12, 8, 20, 12, 1, None, 1, None) == -5  # base not 16-byte aligned
+    assert f(None, 20, wb.data_ptr(), y.data_ptr(), 12, 8, 20, 12, 1, None, 1, None) == -1
+    torch.cuda.synchronize()

@@ -34,3 +34,20 @@ def test_output_shapes_of_the_reference_heads():
     # 84x84 -> 20 -> 9 -> 4 -> 1 (64 features); universe head at 42x42: 20 -> 9 -> 4 -> 2 (Curious_GAN_mario.py:370-371)
     assert [oc.out_size(84, 5, 4), oc.out_size(20, 3, 2), oc.out_size(9, 3, 2), oc.out_size(4, 3, 2)] == [20, 9, 4, 1]
     assert [oc.out_size(84, 3, 2), oc.out_size(41, 3, 2)] == [41, 20]
+
+
+def test_dense_head_matches_torch_autograd():
+    """fc(256) + ELU (Conv_model.py:24): the restatement's three gradients against autograd."""
+    import torch
+    from oracle import conv as oc
+    rng = np.random.RandomState(5)
+    x, w, b = rng.standard_normal((9, 64)), rng.uniform(-0.2, 0.2, (64, 256)), rng.uniform(-0.1, 0.1, 256)
+    y, cache = oc.dense_forward(x, w, b)
+    dy = rng.standard_normal(y.shape)
+    dx, dw, db = oc.dense_backward(dy, w, cache)
+    xt, wt, bt = (torch.tensor(a, dtype=torch.float64, requires_grad=True) for a in (x, w, b))
+    yt = torch.nn.functional.elu(xt @ wt + bt)
+    yt.backward(torch.tensor(dy))
+    np.testing.assert_allclose(y, yt.detach().numpy(), rtol=1e-12, atol=1e-12)
+    for got, ref in ((dx, xt.grad), (dw, wt.grad), (db, bt.grad)):
+        np.testing.assert_allclose(got, ref.numpy(), rtol=1e-10, atol=1e-12)

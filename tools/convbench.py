@@ -25,3 +25,13 @@ for name, hw, spec in (("doom 84x84x4", 84, R.DOOM_HEAD), ("universe(2) 84x84x4"
         dy = torch.randn_like(acts[i + 1])
         t2 = timeit(lambda: L.backward(acts[i], acts[i + 1], dy, need_dx=i > 0))
         print(f"    layer {i}: {L.conv.h}x{L.conv.w}x{L.c_in} -> {L.h_out}x{L.w_out}x{L.c_out}  fwd {t1:8.1f} us {2 * m * B / t1 / 1e6:6.1f} TF/s   bwd {t2:8.1f} us")
+
+for k in (64, 2592, 12800):
+    L = R.DenseLayer(k, 256, rng=np.random.RandomState(0))
+    x = torch.randn(B, k, device="cuda")
+    y = L.forward(x)
+    dy = torch.randn_like(y)
+    t1 = timeit(lambda: L.forward(x))
+    t2 = timeit(lambda: L.backward(x, y, dy))
+    fl = 2.0 * B * (k + 1) * 256
+    print(f"dense {k:6d} -> 256  B={B}: forward {t1:8.1f} us ({fl / t1 / 1e6:6.1f} TFLOP/s)   backward (dW + dX) {t2:8.1f} us ({2 * fl / t2 / 1e6:6.1f} TFLOP/s)")
