@@ -351,18 +351,24 @@ int rlgan_rollout_eval_rows(const rlgan_act_t* act, const rlgan_eval_t* eval, co
  * one: `canon` plus a fragment image `wfrag` of [W ; b] (wfrag_floats floats, zero-filled once) that
  * rlgan_pack_weights / rlgan_apply fill through the int32 map of rlgan_conv_build_map. */
 typedef struct { int32_t h, w, c_in, c_out, k, stride; } rlgan_conv_t;
-typedef struct { int32_t h_out, w_out, k_len, n_params, wfrag_floats, slab_floats; } rlgan_conv_geom_t;
+typedef struct { int32_t h_out, w_out, k_len, n_params, wfrag_floats, slab_floats, wdx_floats; } rlgan_conv_geom_t;
 int rlgan_conv_geometry(const rlgan_conv_t* conv, rlgan_conv_geom_t* out);
 int rlgan_conv_build_map(const rlgan_conv_t* conv, int32_t* map_f);   /* host array of n_params int32 */
+/* Second image for the input gradient (wdx_floats floats, zero-filled once; 0: not available for this
+ * layer): the kernel regrouped by stride phase as MFMA operands.  map_dx: host array of n_params int32,
+ * -1 for the bias; fill the image with rlgan_pack_weights(canon, n, map_f, wfrag, map_dx, wdx). */
+int rlgan_conv_build_dx_map(const rlgan_conv_t* conv, int32_t* map_dx);
 
 /* y[n, h_out, w_out, c_out] = act(conv(x[n, h, w, c_in]) + b); act_elu != 0: ELU, else linear. */
 int rlgan_conv_forward(const rlgan_conv_t* conv, const float* x, const float* wfrag, float* y, int n_images,
                        int act_elu, void* stream);
 /* dz = dy * ELU'(y) elementwise, ELU' taken from the layer OUTPUT y (y > 0 ? 1 : y + 1). */
 int rlgan_elu_backward(const float* dy, const float* y, float* dz, int64_t n, void* stream);
-/* dx[n, h, w, c_in] from dz[n, h_out, w_out, c_out] and the canonical kernel (device, [k*k*c_in, c_out]). */
-int rlgan_conv_backward_input(const rlgan_conv_t* conv, const float* dz, const float* w_canon, float* dx, int n_images,
-                              void* stream);
+/* dx[n, h, w, c_in] from dz[n, h_out, w_out, c_out].  With wdx (see rlgan_conv_build_dx_map): one
+ * implicit GEMM per stride phase on the matrix cores; with wdx NULL: a gather from the canonical kernel
+ * w_canon (device, [k*k*c_in, c_out]) on the vector ALUs, for layers wdx does not cover. */
+int rlgan_conv_backward_input(const rlgan_conv_t* conv, const float* dz, const float* w_canon, const float* wdx, float* dx,
+                              int n_images, void* stream);
 /* grad (canonical order, kernel then bias) = sum over all output pixels.  `slabs`: device scratch of
  * n_slabs * slab_floats floats (one partial image per workgroup, added in a fixed order). */
 int rlgan_conv_backward_weights(const rlgan_conv_t* conv, const float* x, const float* dz, float* slabs, int n_slabs,

@@ -89,7 +89,7 @@ class Conv(C.Structure):
 
 
 class ConvGeom(C.Structure):
-    _fields_ = [(n, _i32) for n in ("h_out", "w_out", "k_len", "n_params", "wfrag_floats", "slab_floats")]
+    _fields_ = [(n, _i32) for n in ("h_out", "w_out", "k_len", "n_params", "wfrag_floats", "slab_floats", "wdx_floats")]
 
 
 class Sample(C.Structure):
@@ -160,9 +160,10 @@ PROTOTYPES = {
     "rlgan_act_rows": [C.POINTER(Act), _vp, _vp],
     "rlgan_conv_geometry": [C.POINTER(Conv), C.POINTER(ConvGeom)],
     "rlgan_conv_build_map": [C.POINTER(Conv), _vp],
+    "rlgan_conv_build_dx_map": [C.POINTER(Conv), _vp],
     "rlgan_conv_forward": [C.POINTER(Conv), _vp, _vp, _vp, _i, _i, _vp],
     "rlgan_elu_backward": [_vp, _vp, _vp, _i64, _vp],
-    "rlgan_conv_backward_input": [C.POINTER(Conv), _vp, _vp, _vp, _i, _vp],
+    "rlgan_conv_backward_input": [C.POINTER(Conv), _vp, _vp, _vp, _vp, _i, _vp],
     "rlgan_conv_backward_weights": [C.POINTER(Conv), _vp, _vp, _vp, _i, _vp, _i, _vp],
     "rlgan_dense_slabs": [_i, _i, _i],
     "rlgan_dense_forward": [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp],

@@ -45,14 +45,24 @@ class ConvLayer:
         self.map_f = torch.from_numpy(m).to(dev)
         self.canon = torch.from_numpy(flat).to(dev)
         self.wfrag = torch.zeros(g.wfrag_floats, dtype=torch.float32, device=dev)
+        # second image for the input gradient: the kernel regrouped by stride phase (absent when the
+        # layer is outside what that kernel covers; the gather kernel then takes over)
+        self.map_dx = self.wdx = None
+        if g.wdx_floats > 0:
+            md = np.empty(self.n_params, np.int32)
+            check(lib.rlgan_conv_build_dx_map(self.conv, md.ctypes.data), "rlgan_conv_build_dx_map")
+            self.map_dx = torch.from_numpy(md).to(dev)
+            self.wdx = torch.zeros(g.wdx_floats, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(self.n_params, dtype=torch.float32, device=dev)
+        self.gather_dx = False   # True: input gradient by the vector-ALU gather even where the MFMA form exists
         self.n_slabs = 1024      # partial weight-gradient images (one per workgroup of the reduction over pixels)
         self._slabs = None
         self.pack()
 
     def pack(self) -> None:
         check(lib.rlgan_pack_weights(self.canon.data_ptr(), self.n_params, self.map_f.data_ptr(), self.wfrag.data_ptr(),
-                                     None, None, _stream()), "rlgan_pack_weights")
+                                     None if self.wdx is None else self.map_dx.data_ptr(),
+                                     None if self.wdx is None else self.wdx.data_ptr(), _stream()), "rlgan_pack_weights")
 
     def kernel_bias(self) -> Tuple[np.ndarray, np.ndarray]:
         f = self.canon.cpu().numpy()
@@ -81,8 +91,9 @@ class ConvLayer:
         if not need_dx:
             return None
         dx = torch.empty_like(x)
-        check(lib.rlgan_conv_backward_input(self.conv, dz.data_ptr(), self.canon.data_ptr(), dx.data_ptr(), n, _stream()),
-              "rlgan_conv_backward_input")
+        use_mfma = self.wdx is not None and not self.gather_dx
+        check(lib.rlgan_conv_backward_input(self.conv, dz.data_ptr(), self.canon.data_ptr(), self.wdx.data_ptr() if use_mfma else None,
+                                            dx.data_ptr(), n, _stream()), "rlgan_conv_backward_input")
         return dx
 
 

@@ -139,19 +139,111 @@ __global__ __launch_bounds__(256) void conv_bwd_input_kernel(const ConvG g, cons
   *(f32x4*)(dx + i * 4) = s;
 }
 
+// ---------------------------------------------------------------- input gradient on the matrix cores
+// Input pixels fall into s*s classes by (y % s, x % s).  Within a class every pixel (y, x) = (s*a + py,
+// s*b + px) is covered by the same kernel taps ky = py + s*u, kx = px + s*v, from output pixels
+// (a - u, b - v): a stride-1 correlation of dZ with the class's share of the kernel, i.e. the GEMM
+//   dX_class[M_c, Cin] = G[M_c, nky*nkx*Cout] * Wc[nky*nkx*Cout, Cin],
+// G gathering dZ rows (zeros where the output pixel lies outside the map), Wc[(u, v, co)][c] =
+// W[ky, kx, c, co].  The Wc of all classes are kept as MFMA B fragments, one image after the other.
+constexpr int MAX_CLASSES = 16;            // stride <= 4
+struct DxClass { int py, px, nky, nkx, na, nb, Kc, NG; };
+__host__ __device__ inline DxClass dx_class(const ConvG& g, int cls) {
+  DxClass c;
+  c.py = cls / g.s; c.px = cls % g.s;
+  c.nky = c.py < g.k ? (g.k - c.py + g.s - 1) / g.s : 0;
+  c.nkx = c.px < g.k ? (g.k - c.px + g.s - 1) / g.s : 0;
+  c.na = c.py < g.H ? (g.H - c.py + g.s - 1) / g.s : 0;
+  c.nb = c.px < g.W ? (g.W - c.px + g.s - 1) / g.s : 0;
+  c.Kc = c.nky * c.nkx * g.Cout;
+  c.NG = cdiv(c.Kc, 16);
+  return c;
+}
+struct DxOff { int off[MAX_CLASSES]; };    // float offset of every class's fragment image
+
+// this lane's four consecutive elements kk0..kk0+3 of the gathered row of input pixel (a, bb) of a class
+// (Cout % 4 == 0: the four share one tap)
+__device__ __forceinline__ f32x4 dz4(const ConvG& g, const DxClass& c, const float* __restrict__ dz, int b, int a, int bb, int kk0) {
+  const f32x4 zero{0.f, 0.f, 0.f, 0.f};
+  if (kk0 >= c.Kc) return zero;
+  const int tap = kk0 / g.Cout, co = kk0 - tap * g.Cout;
+  const int u = tap / c.nkx, v = tap - u * c.nkx;
+  const int oy = a - u, ox = bb - v;
+  if (oy < 0 || oy >= g.Ho || ox < 0 || ox >= g.Wo) return zero;
+  return *(const f32x4*)(dz + (((size_t)b * g.Ho + oy) * g.Wo + ox) * g.Cout + co);
+}
+
+// One wave = 16 input pixels of one class x all Cin column tiles; blockIdx.y = class.
+template <int NT>
+__global__ __launch_bounds__(256) void conv_dx_kernel(const ConvG g, const DxOff offs, const float* __restrict__ dz,
+                                                      const float* __restrict__ wdx, float* __restrict__ dx, int n_images) {
+  const DxClass c = dx_class(g, blockIdx.y);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int per = c.na * c.nb;
+  const long long Ml = (long long)n_images * per;
+  const long long pix0 = ((long long)blockIdx.x * 4 + wave) * 16;
+  if (pix0 >= Ml) return;
+  const long long prow = min(pix0 + (lane & 15), Ml - 1);
+  const int b = (int)(prow / per), r = (int)(prow - (long long)b * per), a = r / c.nb, bb = r - a * c.nb;
+  const int kq = (lane >> 4) * 4;
+  const float* wl = wdx + offs.off[blockIdx.y] + lane * 4;
+  f32x4 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (c.NG > 0) {
+    f32x4 av = dz4(g, c, dz, b, a, bb, kq);
+    f32x4 w[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) w[t] = *(const f32x4*)(wl + t * 256);
+    for (int gi = 0; gi < c.NG; ++gi) {
+      f32x4 an = av, wn[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) wn[t] = w[t];
+      if (gi + 1 < c.NG) {
+        an = dz4(g, c, dz, b, a, bb, 16 * (gi + 1) + kq);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) wn[t] = *(const f32x4*)(wl + ((gi + 1) * NT + t) * 256);
+      }
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], w[t][m], acc[t], 0, 0, 0);
+      }
+      av = an;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) w[t] = wn[t];
+    }
+  }
+  // D fragment: rows (pixels) 4*(lane>>4)+i, column lane&15
+  const int col = lane & 15;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const long long p = pix0 + (lane >> 4) * 4 + i;
+    if (p >= Ml) continue;
+    const int pb = (int)(p / per), pr = (int)(p - (long long)pb * per), pa = pr / c.nb, pbb = pr - pa * c.nb;
+    float* o = dx + (((size_t)pb * g.H + (g.s * pa + c.py)) * g.W + (g.s * pbb + c.px)) * g.Cin;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int n = 16 * t + col;
+      if (n < g.Cin) o[n] = acc[t][i];
+    }
+  }
+}
+
 // ---------------------------------------------------------------- weight gradient
 // dW[K+1, Cout] = [P 1]^T dZ reduced over all output pixels.  A workgroup walks its share of the
-// pixels 64 at a time: patches and dZ rows are staged in LDS, wave w owns the 16-row strips
+// pixels WG_PIX at a time: patches and dZ rows are staged in LDS, wave w owns the 16-row strips
 // w, w+4, ... of K and all column tiles.  Every workgroup writes one partial image (slab); a second
 // kernel adds the slabs in workgroup order, so the result is bitwise reproducible.
-constexpr int WG_PIX = 64;
+constexpr int WG_PIX = 16;   // pixels staged per step: small, so that several workgroups share a compute unit and one's
+                             // staging overlaps another's MFMAs (64 left one workgroup per unit: 2.4x slower)
 template <int NT>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ConvG g, const float* __restrict__ x, const float* __restrict__ dz,
                                                          float* __restrict__ slabs, int M, int pix_per_wg) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int KP = g.NG * 16, ldp = KP + 4, ldz = NT * 16 + 4;
   float* P = lds;                       // [64][ldp]
-  float* Z = lds + WG_PIX * ldp;        // [64][ldz]
+  float* Z = lds + WG_PIX * ldp;        // [WG_PIX][ldz]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nstrips = g.NG, my_strips = (nstrips - wave + 3) / 4;
   constexpr int MAXS = 5;               // K+1 <= 320 rows (the widest layer has 288 + 1)
@@ -247,6 +339,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __r
   }
 }
 
+// fragment images of the input-gradient classes: offsets and total size (0 when the layer is outside
+// what conv_dx_kernel handles: stride > 4 or more than 64 input channels)
+inline int dx_layout(const ConvG& g, DxOff* offs) {
+  if (g.s * g.s > MAX_CLASSES || g.Cin > 64) return 0;
+  const int ntc = cdiv(g.Cin, 16);
+  int total = 0;
+  for (int cls = 0; cls < g.s * g.s; ++cls) {
+    if (offs) offs->off[cls] = total;
+    total += dx_class(g, cls).NG * ntc * 256;
+  }
+  return total;
+}
+
 inline int launched() { return (int)hipGetLastError(); }
 
 }  // namespace
@@ -259,6 +364,27 @@ int rlgan_conv_geometry(const rlgan_conv_t* conv, rlgan_conv_geom_t* out) {
   if (!make_conv(conv, g)) return RLGAN_E_DIMS;
   out->h_out = g.Ho; out->w_out = g.Wo; out->k_len = g.K; out->n_params = (g.K + 1) * g.Cout;
   out->wfrag_floats = g.NG * g.NT * 256; out->slab_floats = g.NG * 16 * g.NT * 16;
+  out->wdx_floats = dx_layout(g, nullptr);
+  return 0;
+}
+
+int rlgan_conv_build_dx_map(const rlgan_conv_t* conv, int32_t* map_dx) {
+  ConvG g;
+  if (!map_dx) return RLGAN_E_ARG;
+  if (!make_conv(conv, g)) return RLGAN_E_DIMS;
+  DxOff offs;
+  if (dx_layout(g, &offs) == 0) return RLGAN_E_DIMS;
+  const int ntc = cdiv(g.Cin, 16);
+  int p = 0;
+  for (int ky = 0; ky < g.k; ++ky)
+    for (int kx = 0; kx < g.k; ++kx) {
+      const int cls = (ky % g.s) * g.s + (kx % g.s);
+      const DxClass c = dx_class(g, cls);
+      const int tap = (ky / g.s) * c.nkx + (kx / g.s);
+      for (int ci = 0; ci < g.Cin; ++ci)
+        for (int co = 0; co < g.Cout; ++co) map_dx[p++] = offs.off[cls] + frag_offset(ntc, tap * g.Cout + co, ci);
+    }
+  for (int n = 0; n < g.Cout; ++n) map_dx[p++] = -1;     // the bias takes no part
   return 0;
 }
 
@@ -297,11 +423,27 @@ int rlgan_elu_backward(const float* dy, const float* y, float* dz, int64_t n, vo
   return launched();
 }
 
-int rlgan_conv_backward_input(const rlgan_conv_t* conv, const float* dz, const float* w_canon, float* dx, int n_images,
-                              void* stream) {
+int rlgan_conv_backward_input(const rlgan_conv_t* conv, const float* dz, const float* w_canon, const float* wdx, float* dx,
+                              int n_images, void* stream) {
   ConvG g;
   if (!make_conv(conv, g)) return RLGAN_E_DIMS;
-  if (!dz || !w_canon || !dx || n_images <= 0) return RLGAN_E_ARG;
+  if (!dz || (!w_canon && !wdx) || !dx || n_images <= 0) return RLGAN_E_ARG;
+  if (wdx) {
+    DxOff offs;
+    if (dx_layout(g, &offs) == 0) return RLGAN_E_DIMS;
+    const long long per = (long long)cdiv(g.H, g.s) * cdiv(g.W, g.s);          // pixels per image of the largest class
+    const long long groups = cdiv((long long)n_images * per, 64);
+    if (groups > 0x7fffffffll) return RLGAN_E_ALIGN;
+    const dim3 grid((unsigned)groups, g.s * g.s), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    switch (cdiv(g.Cin, 16)) {
+      case 1: hipLaunchKernelGGL(conv_dx_kernel<1>, grid, block, 0, st, g, offs, dz, wdx, dx, n_images); break;
+      case 2: hipLaunchKernelGGL(conv_dx_kernel<2>, grid, block, 0, st, g, offs, dz, wdx, dx, n_images); break;
+      case 3: hipLaunchKernelGGL(conv_dx_kernel<3>, grid, block, 0, st, g, offs, dz, wdx, dx, n_images); break;
+      default: hipLaunchKernelGGL(conv_dx_kernel<4>, grid, block, 0, st, g, offs, dz, wdx, dx, n_images); break;
+    }
+    return launched();
+  }
   const size_t total4 = (size_t)n_images * g.H * g.W * (g.Cin / 4);
   hipLaunchKernelGGL(conv_bwd_input_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      g, dz, w_canon, dx, total4);

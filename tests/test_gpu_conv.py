@@ -110,3 +110,21 @@ def test_dense_argument_errors():
     assert f(x.data_ptr() + 4, 20, wb.data_ptr(), y.data_ptr(), 12, 8, 20, 12, 1, None, 1, None) == -5  # base not 16-byte aligned
     assert f(None, 20, wb.data_ptr(), y.data_ptr(), 12, 8, 20, 12, 1, None, 1, None) == -1
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("h,cin,cout,k,st", [(84, 4, 8, 5, 4), (41, 32, 32, 3, 2), (9, 16, 32, 3, 2), (12, 8, 16, 3, 3), (10, 4, 4, 2, 4)])
+def test_input_gradient_two_ways(h, cin, cout, k, st):
+    """The stride-phase MFMA form of dX against the gather from the canonical kernel, including a layer
+    whose stride exceeds its kernel (pixels no patch covers get a zero gradient)."""
+    import rl_gan_amd as R
+    from gpu_util import close
+    rng = np.random.RandomState(h + k)
+    L = R.ConvLayer(h, h, cin, cout, k, st, rng=rng, bias_init=0.01)
+    assert L.wdx is not None
+    x = torch.rand(3, h, h, cin, device="cuda")
+    y = L.forward(x)
+    dy = torch.randn_like(y)
+    a = L.backward(x, y, dy).clone()
+    L.gather_dx = True
+    b = L.backward(x, y, dy)
+    close(a.cpu().numpy(), b.cpu().numpy().astype(np.float64), what="dX mfma vs gather")
