@@ -366,13 +366,15 @@ int rlgan_conv_forward(const rlgan_conv_t* conv, const float* x, const float* wf
 int rlgan_elu_backward(const float* dy, const float* y, float* dz, int64_t n, void* stream);
 /* dx[n, h, w, c_in] from dz[n, h_out, w_out, c_out].  With wdx (see rlgan_conv_build_dx_map): one
  * implicit GEMM per stride phase on the matrix cores; with wdx NULL: a gather from the canonical kernel
- * w_canon (device, [k*k*c_in, c_out]) on the vector ALUs, for layers wdx does not cover. */
-int rlgan_conv_backward_input(const rlgan_conv_t* conv, const float* dz, const float* w_canon, const float* wdx, float* dx,
-                              int n_images, void* stream);
+ * w_canon (device, [k*k*c_in, c_out]) on the vector ALUs, for layers wdx does not cover.
+ * y_elu (optional, needs wdx): the layer's output; `dz` is then dy and is multiplied by ELU'(y) as it is
+ * read, which saves the separate rlgan_elu_backward pass. */
+int rlgan_conv_backward_input(const rlgan_conv_t* conv, const float* dz, const float* y_elu, const float* w_canon, const float* wdx,
+                              float* dx, int n_images, void* stream);
 /* grad (canonical order, kernel then bias) = sum over all output pixels.  `slabs`: device scratch of
- * n_slabs * slab_floats floats (one partial image per workgroup, added in a fixed order). */
-int rlgan_conv_backward_weights(const rlgan_conv_t* conv, const float* x, const float* dz, float* slabs, int n_slabs,
-                                float* grad, int n_images, void* stream);
+ * n_slabs * slab_floats floats (one partial image per workgroup, added in a fixed order).  y_elu as above. */
+int rlgan_conv_backward_weights(const rlgan_conv_t* conv, const float* x, const float* dz, const float* y_elu, float* slabs,
+                                int n_slabs, float* grad, int n_images, void* stream);
 
 /* ---- fully connected head of the pixel encoders (Conv_model.py:24 `fc`, :52-56 `dense1` + elu) ------
  * wb: canonical parameters on the device, the [k, n] kernel (row-major, TF layout) followed by the

@@ -163,8 +163,8 @@ PROTOTYPES = {
     "rlgan_conv_build_dx_map": [C.POINTER(Conv), _vp],
     "rlgan_conv_forward": [C.POINTER(Conv), _vp, _vp, _vp, _i, _i, _vp],
     "rlgan_elu_backward": [_vp, _vp, _vp, _i64, _vp],
-    "rlgan_conv_backward_input": [C.POINTER(Conv), _vp, _vp, _vp, _vp, _i, _vp],
-    "rlgan_conv_backward_weights": [C.POINTER(Conv), _vp, _vp, _vp, _i, _vp, _i, _vp],
+    "rlgan_conv_backward_input": [C.POINTER(Conv), _vp, _vp, _vp, _vp, _vp, _i, _vp],
+    "rlgan_conv_backward_weights": [C.POINTER(Conv), _vp, _vp, _vp, _vp, _i, _vp, _i, _vp],
     "rlgan_dense_slabs": [_i, _i, _i],
     "rlgan_dense_forward": [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp],
     "rlgan_dense_backward_input": [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp],

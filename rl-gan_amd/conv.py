@@ -80,20 +80,23 @@ class ConvLayer:
     def backward(self, x: torch.Tensor, y: torch.Tensor, dy: torch.Tensor, need_dx: bool = True, act: bool = True):
         """Gradients of this layer: fills self.grad (kernel then bias), returns dx or None."""
         n = x.shape[0]
-        dz = dy
-        if act:
+        use_mfma = self.wdx is not None and not self.gather_dx
+        # ELU' is applied by the consumers as they read dy (no pass of its own) unless the gather kernel runs
+        fuse = act and (use_mfma or not need_dx)
+        dz, yel = dy, (y.data_ptr() if fuse else None)
+        if act and not fuse:
             dz = torch.empty_like(dy)
             check(lib.rlgan_elu_backward(dy.data_ptr(), y.data_ptr(), dz.data_ptr(), dy.numel(), _stream()), "rlgan_elu_backward")
         if self._slabs is None:
             self._slabs = torch.empty(self.n_slabs * self.geom.slab_floats, dtype=torch.float32, device=x.device)
-        check(lib.rlgan_conv_backward_weights(self.conv, x.data_ptr(), dz.data_ptr(), self._slabs.data_ptr(), self.n_slabs,
+        check(lib.rlgan_conv_backward_weights(self.conv, x.data_ptr(), dz.data_ptr(), yel, self._slabs.data_ptr(), self.n_slabs,
                                               self.grad.data_ptr(), n, _stream()), "rlgan_conv_backward_weights")
         if not need_dx:
             return None
         dx = torch.empty_like(x)
-        use_mfma = self.wdx is not None and not self.gather_dx
-        check(lib.rlgan_conv_backward_input(self.conv, dz.data_ptr(), self.canon.data_ptr(), self.wdx.data_ptr() if use_mfma else None,
-                                            dx.data_ptr(), n, _stream()), "rlgan_conv_backward_input")
+        check(lib.rlgan_conv_backward_input(self.conv, dz.data_ptr(), yel, self.canon.data_ptr(),
+                                            self.wdx.data_ptr() if use_mfma else None, dx.data_ptr(), n, _stream()),
+              "rlgan_conv_backward_input")
         return dx
 
 

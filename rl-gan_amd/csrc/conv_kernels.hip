@@ -31,6 +31,7 @@ inline bool make_conv(const rlgan_conv_t* c, ConvG& g) {
 }
 
 __device__ __forceinline__ float elu_f(float z) { return z > 0.f ? z : expm1f(z); }
+__device__ __forceinline__ float elu_d(float y) { return y > 0.f ? 1.f : y + 1.f; }   // ELU' from the layer output
 
 // this lane's four consecutive patch elements k0..k0+3 of output pixel `pix` (k0 % 4 == 0; rowlen % 4 == 0,
 // so the four never straddle a kernel row); element K is the constant 1 of the bias row, zeros after it
@@ -97,8 +98,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvG g, const floa
 __global__ void elu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dz, size_t n) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const float v = y[i];
-  dz[i] = dy[i] * (v > 0.f ? 1.f : v + 1.f);
+  dz[i] = dy[i] * elu_d(y[i]);
 }
 
 // ---------------------------------------------------------------- input gradient
@@ -163,20 +163,29 @@ struct DxOff { int off[MAX_CLASSES]; };    // float offset of every class's frag
 
 // this lane's four consecutive elements kk0..kk0+3 of the gathered row of input pixel (a, bb) of a class
 // (Cout % 4 == 0: the four share one tap)
-__device__ __forceinline__ f32x4 dz4(const ConvG& g, const DxClass& c, const float* __restrict__ dz, int b, int a, int bb, int kk0) {
+__device__ __forceinline__ f32x4 dz4(const ConvG& g, const DxClass& c, const float* __restrict__ dz, const float* __restrict__ yelu,
+                                    int b, int a, int bb, int kk0) {
   const f32x4 zero{0.f, 0.f, 0.f, 0.f};
   if (kk0 >= c.Kc) return zero;
   const int tap = kk0 / g.Cout, co = kk0 - tap * g.Cout;
   const int u = tap / c.nkx, v = tap - u * c.nkx;
   const int oy = a - u, ox = bb - v;
   if (oy < 0 || oy >= g.Ho || ox < 0 || ox >= g.Wo) return zero;
-  return *(const f32x4*)(dz + (((size_t)b * g.Ho + oy) * g.Wo + ox) * g.Cout + co);
+  const size_t at = (((size_t)b * g.Ho + oy) * g.Wo + ox) * g.Cout + co;
+  f32x4 d = *(const f32x4*)(dz + at);
+  if (yelu) {                                                     // dz is dY: times ELU'(y) on the way in
+    const f32x4 yv = *(const f32x4*)(yelu + at);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) d[i] *= elu_d(yv[i]);
+  }
+  return d;
 }
 
 // One wave = 16 input pixels of one class x all Cin column tiles; blockIdx.y = class.
 template <int NT>
 __global__ __launch_bounds__(256) void conv_dx_kernel(const ConvG g, const DxOff offs, const float* __restrict__ dz,
-                                                      const float* __restrict__ wdx, float* __restrict__ dx, int n_images) {
+                                                      const float* __restrict__ yelu, const float* __restrict__ wdx,
+                                                      float* __restrict__ dx, int n_images) {
   const DxClass c = dx_class(g, blockIdx.y);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int per = c.na * c.nb;
@@ -191,7 +200,7 @@ __global__ __launch_bounds__(256) void conv_dx_kernel(const ConvG g, const DxOff
 #pragma unroll
   for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   if (c.NG > 0) {
-    f32x4 av = dz4(g, c, dz, b, a, bb, kq);
+    f32x4 av = dz4(g, c, dz, yelu, b, a, bb, kq);
     f32x4 w[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) w[t] = *(const f32x4*)(wl + t * 256);
@@ -200,7 +209,7 @@ __global__ __launch_bounds__(256) void conv_dx_kernel(const ConvG g, const DxOff
 #pragma unroll
       for (int t = 0; t < NT; ++t) wn[t] = w[t];
       if (gi + 1 < c.NG) {
-        an = dz4(g, c, dz, b, a, bb, 16 * (gi + 1) + kq);
+        an = dz4(g, c, dz, yelu, b, a, bb, 16 * (gi + 1) + kq);
 #pragma unroll
         for (int t = 0; t < NT; ++t) wn[t] = *(const f32x4*)(wl + ((gi + 1) * NT + t) * 256);
       }
@@ -239,10 +248,10 @@ constexpr int WG_PIX = 16;   // pixels staged per step: small, so that several w
                              // staging overlaps another's MFMAs (64 left one workgroup per unit: 2.4x slower)
 template <int NT>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ConvG g, const float* __restrict__ x, const float* __restrict__ dz,
-                                                         float* __restrict__ slabs, int M, int pix_per_wg) {
+                                                         const float* __restrict__ yelu, float* __restrict__ slabs, int M, int pix_per_wg) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int KP = g.NG * 16, ldp = KP + 4, ldz = NT * 16 + 4;
-  float* P = lds;                       // [64][ldp]
+  float* P = lds;                       // [WG_PIX][ldp]
   float* Z = lds + WG_PIX * ldp;        // [WG_PIX][ldz]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nstrips = g.NG, my_strips = (nstrips - wave + 3) / 4;
@@ -270,7 +279,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ConvG g, const fl
     for (int e = threadIdx.x; e < WG_PIX * NT * 16; e += 256) {
       const int pl = e / (NT * 16), n = e - pl * (NT * 16);
       const int p = p0 + pl;
-      Z[pl * ldz + n] = (p < p_end && n < g.Cout) ? dz[(size_t)p * g.Cout + n] : 0.f;
+      float v = 0.f;
+      if (p < p_end && n < g.Cout) {
+        v = dz[(size_t)p * g.Cout + n];
+        if (yelu) v *= elu_d(yelu[(size_t)p * g.Cout + n]);      // dz is dY: times ELU'(y) on the way in
+      }
+      Z[pl * ldz + n] = v;
     }
     __syncthreads();
     // A[row = patch element][kk = pixel], B[kk = pixel][col = channel]
@@ -423,11 +437,11 @@ int rlgan_elu_backward(const float* dy, const float* y, float* dz, int64_t n, vo
   return launched();
 }
 
-int rlgan_conv_backward_input(const rlgan_conv_t* conv, const float* dz, const float* w_canon, const float* wdx, float* dx,
-                              int n_images, void* stream) {
+int rlgan_conv_backward_input(const rlgan_conv_t* conv, const float* dz, const float* y_elu, const float* w_canon, const float* wdx,
+                              float* dx, int n_images, void* stream) {
   ConvG g;
   if (!make_conv(conv, g)) return RLGAN_E_DIMS;
-  if (!dz || (!w_canon && !wdx) || !dx || n_images <= 0) return RLGAN_E_ARG;
+  if (!dz || (!w_canon && !wdx) || !dx || n_images <= 0 || (y_elu && !wdx)) return RLGAN_E_ARG;
   if (wdx) {
     DxOff offs;
     if (dx_layout(g, &offs) == 0) return RLGAN_E_DIMS;
@@ -437,10 +451,10 @@ int rlgan_conv_backward_input(const rlgan_conv_t* conv, const float* dz, const f
     const dim3 grid((unsigned)groups, g.s * g.s), block(256);
     hipStream_t st = (hipStream_t)stream;
     switch (cdiv(g.Cin, 16)) {
-      case 1: hipLaunchKernelGGL(conv_dx_kernel<1>, grid, block, 0, st, g, offs, dz, wdx, dx, n_images); break;
-      case 2: hipLaunchKernelGGL(conv_dx_kernel<2>, grid, block, 0, st, g, offs, dz, wdx, dx, n_images); break;
-      case 3: hipLaunchKernelGGL(conv_dx_kernel<3>, grid, block, 0, st, g, offs, dz, wdx, dx, n_images); break;
-      default: hipLaunchKernelGGL(conv_dx_kernel<4>, grid, block, 0, st, g, offs, dz, wdx, dx, n_images); break;
+      case 1: hipLaunchKernelGGL(conv_dx_kernel<1>, grid, block, 0, st, g, offs, dz, y_elu, wdx, dx, n_images); break;
+      case 2: hipLaunchKernelGGL(conv_dx_kernel<2>, grid, block, 0, st, g, offs, dz, y_elu, wdx, dx, n_images); break;
+      case 3: hipLaunchKernelGGL(conv_dx_kernel<3>, grid, block, 0, st, g, offs, dz, y_elu, wdx, dx, n_images); break;
+      default: hipLaunchKernelGGL(conv_dx_kernel<4>, grid, block, 0, st, g, offs, dz, y_elu, wdx, dx, n_images); break;
     }
     return launched();
   }
@@ -450,8 +464,8 @@ int rlgan_conv_backward_input(const rlgan_conv_t* conv, const float* dz, const f
   return launched();
 }
 
-int rlgan_conv_backward_weights(const rlgan_conv_t* conv, const float* x, const float* dz, float* slabs, int n_slabs,
-                                float* grad, int n_images, void* stream) {
+int rlgan_conv_backward_weights(const rlgan_conv_t* conv, const float* x, const float* dz, const float* y_elu, float* slabs,
+                                int n_slabs, float* grad, int n_images, void* stream) {
   ConvG g;
   if (!make_conv(conv, g)) return RLGAN_E_DIMS;
   if (!x || !dz || !slabs || !grad || n_images <= 0 || n_slabs <= 0) return RLGAN_E_ARG;
@@ -468,7 +482,7 @@ int rlgan_conv_backward_weights(const rlgan_conv_t* conv, const float* x, const 
 #define RLGAN_WG(NTV)                                                                                              \
   {                                                                                                                \
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<NTV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-    hipLaunchKernelGGL(conv_wgrad_kernel<NTV>, grid, block, lds, st, g, x, dz, slabs, M, per);                     \
+    hipLaunchKernelGGL(conv_wgrad_kernel<NTV>, grid, block, lds, st, g, x, dz, y_elu, slabs, M, per);                     \
   }
   switch (g.NT) {
     case 1: RLGAN_WG(1) break;

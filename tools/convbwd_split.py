@@ -21,9 +21,9 @@ for (h, cin, cout, k, s) in ((84, 4, 32, 3, 2), (41, 32, 32, 3, 2), (20, 32, 32,
     L.backward(x, y, dy)
     dx = torch.empty_like(x)
     t0 = timeit(lambda: check(lib.rlgan_elu_backward(dy.data_ptr(), y.data_ptr(), dz.data_ptr(), dy.numel(), _stream())))
-    t1 = timeit(lambda: check(lib.rlgan_conv_backward_weights(L.conv, x.data_ptr(), dz.data_ptr(), L._slabs.data_ptr(), L.n_slabs,
+    t1 = timeit(lambda: check(lib.rlgan_conv_backward_weights(L.conv, x.data_ptr(), dz.data_ptr(), None, L._slabs.data_ptr(), L.n_slabs,
                                                               L.grad.data_ptr(), B, _stream())))
-    t2 = timeit(lambda: check(lib.rlgan_conv_backward_input(L.conv, dz.data_ptr(), L.canon.data_ptr(), None, dx.data_ptr(), B, _stream())))
-    t3 = timeit(lambda: check(lib.rlgan_conv_backward_input(L.conv, dz.data_ptr(), L.canon.data_ptr(), L.wdx.data_ptr(), dx.data_ptr(), B, _stream())))
+    t2 = timeit(lambda: check(lib.rlgan_conv_backward_input(L.conv, dz.data_ptr(), None, L.canon.data_ptr(), None, dx.data_ptr(), B, _stream())))
+    t3 = timeit(lambda: check(lib.rlgan_conv_backward_input(L.conv, dz.data_ptr(), None, L.canon.data_ptr(), L.wdx.data_ptr(), dx.data_ptr(), B, _stream())))
     macs = L.h_out * L.w_out * k * k * cin * cout * B
     print(f"{h}x{h}x{cin} -> {L.h_out}x{L.w_out}x{cout} k{k}/s{s}: elu' {t0:7.1f} us  dW {t1:8.1f} us ({2 * macs / t1 / 1e6:5.1f} TF/s)  dX gather {t2:8.1f} us ({2 * macs / t2 / 1e6:5.1f} TF/s)  dX mfma {t3:8.1f} us ({2 * macs / t3 / 1e6:5.1f} TF/s)")
