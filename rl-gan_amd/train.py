@@ -71,8 +71,61 @@ class Agent:
                 out[f"{scope}/{name}"] = value
         return out
 
-    def save_checkpoint(self, path: str) -> None:
-        np.savez(path, **{k.replace("/", "."): v for k, v in self.variables().items()})
+    def _slot_tables(self):
+        """(optimizer scope, variable scope, network, flat slot tensor, TF slot suffix): what a
+        `tf.train.Saver()` over all global variables also holds besides the weights, i.e. the RMSProp
+        accumulators of `C_train` (critic and, through the missing var_list, actor variables, DDPG.py:148)
+        and `A_train` (DDPG.py:112) and the Adam moments of the D and G optimizers (Curious_GAN.py:45,142)."""
+        a, c, g, d = self.actor.state, self.critic.state, self.generator.state, self.discriminator.state
+        c.ensure_actor_slots(a.e.n_params)
+        return (("C_train", "Critic/eval_net", c.e, c.ms, "RMSProp"), ("C_train", "Actor/eval_net", a.e, c.ms_actor, "RMSProp"),
+                ("A_train", "Actor/eval_net", a.e, a.ms, "RMSProp"),
+                ("D_train", "Discriminator/eval_net", d.net, d.m, "Adam"), ("D_train", "Discriminator/eval_net", d.net, d.v, "Adam_1"),
+                ("G_train", "Generator/eval_net", g.net, g.m, "Adam"), ("G_train", "Generator/eval_net", g.net, g.v, "Adam_1"))
+
+    def training_state(self) -> Dict[str, np.ndarray]:
+        """Everything besides the weights that the next update depends on: optimizer slots per variable,
+        Adam step counts, target-replacement counters, the exploration scale and NumPy's global stream
+        (which the reference's Saver cannot hold: it restarts `var` and the stream on restore).  The replay
+        memory and the environment are not part of it, as in the reference."""
+        out: Dict[str, np.ndarray] = {}
+        for opt, scope, net, slot, suffix in self._slot_tables():
+            flat, o = slot.detach().cpu().numpy(), 0
+            for name, shape in net.table:
+                k = int(np.prod(shape))
+                out[f"{opt}/{scope}/{name}/{suffix}"] = flat[o:o + k].reshape(shape).copy()
+                o += k
+        out["D_train/step"] = self.discriminator.state.step.cpu().numpy()
+        out["G_train/step"] = self.generator.state.step.cpu().numpy()
+        out["Actor/t_replace_counter"] = self.actor.state.counter.cpu().numpy()
+        out["Critic/t_replace_counter"] = self.critic.state.counter.cpu().numpy()
+        out["var"] = np.array(self.var, np.float64)
+        kind, key, pos, has_gauss, cached = np.random.get_state()
+        assert kind == "MT19937"
+        out["np_random/key"] = np.asarray(key, np.uint32)
+        out["np_random/pos_gauss"] = np.array([pos, has_gauss], np.int64)
+        out["np_random/cached_gaussian"] = np.array(cached, np.float64)
+        return out
+
+    def _load_training_state(self, flat: Dict[str, np.ndarray]) -> None:
+        import torch
+        for opt, scope, net, slot, suffix in self._slot_tables():
+            vec = np.concatenate([np.asarray(flat[f"{opt}/{scope}/{name}/{suffix}"], np.float32).reshape(-1) for name, _ in net.table])
+            slot.copy_(torch.from_numpy(vec))
+        for key, t in (("D_train/step", self.discriminator.state.step), ("G_train/step", self.generator.state.step),
+                       ("Actor/t_replace_counter", self.actor.state.counter), ("Critic/t_replace_counter", self.critic.state.counter)):
+            t.copy_(torch.from_numpy(np.asarray(flat[key], np.int32)))
+        self.var = float(flat["var"])
+        pos, has_gauss = (int(v) for v in flat["np_random/pos_gauss"])
+        np.random.set_state(("MT19937", np.asarray(flat["np_random/key"], np.uint32), pos, has_gauss, float(flat["np_random/cached_gaussian"])))
+
+    def save_checkpoint(self, path: str, training_state: bool = True) -> None:
+        """Weights under their TensorFlow variable names; with training_state also the optimizer slots,
+        counters, exploration scale and RNG stream, so that the next `learn` calls continue bit for bit."""
+        items = dict(self.variables())
+        if training_state:
+            items.update(self.training_state())
+        np.savez(path, **{k.replace("/", "."): v for k, v in items.items()})
 
     def load_checkpoint(self, path: str) -> None:
         data = np.load(path)                         # arrays only: nothing in the file is executed
@@ -81,6 +134,8 @@ class Agent:
                            ("Critic/eval_net", self.critic.state.e), ("Critic/target_net", self.critic.state.t),
                            ("Generator/eval_net", self.generator.state.net), ("Discriminator/eval_net", self.discriminator.state.net)):
             net.set_tensors({name: flat[f"{scope}/{name}"] for name, _ in net.table})
+        if "var" in flat:
+            self._load_training_state(flat)
 
 
 def train(agent: Agent, episodes: Optional[int] = None, log: Optional[Callable[[str], None]] = print) -> List[dict]:

@@ -227,5 +227,17 @@ def test_reference_training_loops_and_checkpoint_round_trip(tmp_path):
         np.testing.assert_array_equal(a.get_flat(), b.get_flat())
     s = np.linspace(-1, 1, 7)
     np.testing.assert_array_equal(other.actor.choose_action(s), ag.actor.choose_action(s))     # fragment images followed
+    # optimizer slots, Adam steps, replace counters, exploration scale and the NumPy stream came along:
+    # the same batch moves both agents to bit-identical weights
+    assert other.var == ag.var and other.actor.t_replace_counter == ag.actor.t_replace_counter
+    assert np.random.get_state()[2] == int(np.load(path)["np_random.pos_gauss"][0])
+    b = ag.M.data[:16]
+    for x in (ag, other):
+        bs, bs_, bg, ba, br = b[:, :7], b[:, 7:14], b[:, 14:21], b[:, 21:23], b[:, -1:]
+        x.critic.learn(bs, ba, br, bs_); x.actor.learn(bs)
+        x.discriminator.learn(bg, bs_, bs, ba); x.generator.learn(bs, ba)
+    for a, b2 in ((other.actor.state.e, ag.actor.state.e), (other.critic.state.e, ag.critic.state.e),
+                  (other.generator.state.net, ag.generator.state.net), (other.discriminator.state.net, ag.discriminator.state.net)):
+        np.testing.assert_array_equal(a.get_flat(), b2.get_flat())
     h2 = R.train_DDPG(R.Agent(cfg), episodes=2, log=None)
     assert len(h2) == 2 and all(np.isfinite(h["R"]) for h in h2)
