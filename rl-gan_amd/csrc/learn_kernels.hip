@@ -37,17 +37,17 @@ __device__ __forceinline__ void critic_tile(const CriticArgs& A, float* smem, in
   const float* st_s = stage; const float* st_a = stage + S; const float* st_r = stage + S + Ad; const float* st_sn = stage + S + Ad + 1;
 
   // target action a' = actor_target(s')
-  Pre<NT_H, 2> p_at; p_at.issue(A.actor_t.wf + A.ga.offf[0]);
+  FwdPre<NET_ACTOR> p_at; p_at.issue(A.actor_t.wf + A.ga.offf[0]);
   stage_rows(stage, row0, A.n_rows, gin(A.s, S), gin(A.a, Ad), gin(A.r, 1), gin(A.s_next, S));
   __syncthreads();
   load_x0(t.x0, row0, A.n_rows, lin(st_sn, STAGE_LD, S), nil(), nil(), nullptr);
   __syncthreads();
-  Pre<NT_H, 2> p_ct;
+  FwdPre<NET_CRITIC> p_ct;
   net_forward<NET_ACTOR, false>(A.actor_t.wf, A.ga, t, none, p_at, [&] { p_ct.issue(A.critic_t.wf + A.gc.offf[0]); });
   // q' = critic_target(s', a')
   load_x0(t.x0, row0, A.n_rows, lin(st_sn, STAGE_LD, S), lin(t.out, LD_O, Ad), nil(), nullptr);
   __syncthreads();
-  Pre<NT_H, 2> p_ce;
+  FwdPre<NET_CRITIC> p_ce;
   net_forward<NET_CRITIC, false>(A.critic_t.wf, A.gc, t, none, p_ct, [&] { p_ce.issue(A.critic_e.wf + A.gc.offf[0]); });
   if (threadIdx.x < ROWS) {
     const float rew = st_r[threadIdx.x * STAGE_LD];                        // 0 beyond n_rows
@@ -71,7 +71,7 @@ __device__ __forceinline__ void critic_tile(const CriticArgs& A, float* smem, in
   fill_out_col0(t.out, small + 16);
   __syncthreads();
   if (A.train_actor) {
-    Pre<NT_H, 2> p_ae;
+    FwdPre<NET_ACTOR> p_ae;
     net_backward<NET_CRITIC, true, true>(A.critic_e.wb, A.gc, t, wc, p_cb, [&] { p_ae.issue(A.actor_e.wf + A.ga.offf[0]); });
     // gradient continues through the tensor actor.a: TanhGrad at the FED action (DDPG.py:148,175)
     {
@@ -130,10 +130,10 @@ __device__ __forceinline__ void actor_tile(const ActorArgs& A, float* smem, int 
   const ActsG none{};
   const ActsG wa = acts_at(A.acts_a.p, row0, A.ga.ld3);
 
-  Pre<NT_H, 2> p_a; p_a.issue(A.actor_e.wf + A.ga.offf[0]);
+  FwdPre<NET_ACTOR> p_a; p_a.issue(A.actor_e.wf + A.ga.offf[0]);
   load_x0(ta.x0, row0, A.n_rows, gin(A.s, S), nil(), nil(), wa.x0);
   __syncthreads();
-  Pre<NT_H, 2> p_c;
+  FwdPre<NET_CRITIC> p_c;
   net_forward<NET_ACTOR, true>(A.actor_e.wf, A.ga, ta, wa, p_a, [&] { p_c.issue(A.critic_e.wf + A.gc.offf[0]); });   // a = actor_eval(s), live
   load_x0(tc.x0, row0, A.n_rows, lin(ta.x0, LD_X0, S), lin(ta.out, LD_O, Ad), nil(), nullptr);   // s: from the actor's input tile
   __syncthreads();
@@ -189,7 +189,7 @@ __device__ __forceinline__ void disc_tile(const DiscArgs& A, float* smem, int ti
   const int S = A.gd.S, Ad = A.gd.A;
   float* stage = small + 64;                        // [16][STAGE_LD]: s | g | a | s' of the tile's rows
   float ltot = 0.f;
-  Pre<NT_H, 2> p_f; p_f.issue(A.disc.wf + A.gd.offf[0]);
+  FwdPre<NET_DISC> p_f; p_f.issue(A.disc.wf + A.gd.offf[0]);
   stage_rows(stage, row0, A.n_rows, gin(A.s, S), gin(A.g, S), gin(A.a, Ad), gin(A.s_next, S));
   __syncthreads();
 #pragma unroll 1
@@ -248,10 +248,10 @@ __device__ __forceinline__ void gen_tile(const GenArgs& A, float* smem, int tile
   const ActsG none{};
   const ActsG wg = acts_at(A.acts_g.p, row0, A.gg.ld3);
 
-  Pre<NT_H, 2> p_g; p_g.issue(A.gen.wf + A.gg.offf[0]);
+  FwdPre<NET_GEN> p_g; p_g.issue(A.gen.wf + A.gg.offf[0]);
   load_x0(tg.x0, row0, A.n_rows, gin(A.s, S), gin(A.a, Ad), nil(), wg.x0);
   __syncthreads();
-  Pre<NT_H, 2> p_d;
+  FwdPre<NET_DISC> p_d;
   net_forward<NET_GEN, true>(A.gen.wf, A.gg, tg, wg, p_g, [&] { p_d.issue(A.disc.wf + A.gd.offf[0]); });   // g^ = G(s, a), live
   load_x0(td.x0, row0, A.n_rows, lin(tg.x0, LD_X0, S), lin(tg.out, LD_O, S), lin(tg.x0 + S, LD_X0, Ad), nullptr);   // s, a: from G's input tile
   __syncthreads();
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(THREADS) void mlp_forward_kernel(const FwdArgs A) {
   const int row0 = blockIdx.x * ROWS;
   const int S = A.g.S, Ad = A.g.A;
   const ActsG none{};
-  Pre<NT_H, 2> p1; p1.issue(A.net.wf + A.g.offf[0]);
+  FwdPre<KIND> p1; p1.issue(A.net.wf + A.g.offf[0]);
   if (KIND == NET_ACTOR) load_x0(t.x0, row0, A.n_rows, gin(A.s, S), nil(), nil(), nullptr);
   else if (KIND == NET_DISC) load_x0(t.x0, row0, A.n_rows, gin(A.s, S), gin(A.x, S), gin(A.a, Ad), nullptr);
   else load_x0(t.x0, row0, A.n_rows, gin(A.s, S), gin(A.a, Ad), nil(), nullptr);

@@ -48,6 +48,8 @@ struct Geo {
 
 __host__ __device__ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+__host__ __device__ constexpr int first_groups(int kind) { return kind == NET_DISC ? 2 : 1; }
+
 __host__ __device__ inline bool make_geo(int kind, int S, int A, Geo& g) {
   if (S < 1 || A < 1) return false;
   g.S = S; g.A = A;
@@ -58,12 +60,15 @@ __host__ __device__ inline bool make_geo(int kind, int S, int A, Geo& g) {
     case NET_DISC:   g.K0 = 2 * S + A; g.N3 = 10; g.NOUT = 1; break;
     default: return false;
   }
-  if (g.K0 > 16 || g.NOUT > 15) return false;
+  // first layer: inputs plus the constant-1 column in one k-group of 16, two for the discriminator
+  // (its 2S + A = 16 inputs fill a group by themselves)
+  const int ng1 = first_groups(kind);
+  if (g.K0 + 1 > 16 * ng1 || g.K0 > 16 || g.NOUT > 15) return false;
   g.NT3 = cdiv(g.N3, 16);
   g.K[0] = g.K0; g.N[0] = HID; g.K[1] = HID; g.N[1] = HID; g.K[2] = HID; g.N[2] = g.N3; g.K[3] = g.N3; g.N[3] = g.NOUT;
   int of = 0, ob = 0, og = 0, np_ = 0;
   for (int l = 0; l < 4; ++l) {
-    g.ngf[l] = l == 0 ? 2 : cdiv(g.K[l] + 1, 16); g.ntf[l] = cdiv(g.N[l], 16); g.offf[l] = of; of += g.ngf[l] * g.ntf[l] * 256;
+    g.ngf[l] = l == 0 ? ng1 : cdiv(g.K[l] + 1, 16); g.ntf[l] = cdiv(g.N[l], 16); g.offf[l] = of; of += g.ngf[l] * g.ntf[l] * 256;
     g.ngb[l] = cdiv(g.N[l], 16);                  g.ntb[l] = cdiv(g.K[l], 16); g.offb[l] = ob; ob += g.ngb[l] * g.ntb[l] * 256;
     g.kp[l] = 16 * cdiv(g.K[l] + 1, 16); g.np[l] = 16 * g.ntf[l]; g.goff[l] = og; og += g.kp[l] * g.np[l];
     np_ += (g.K[l] + 1) * g.N[l];
@@ -128,6 +133,7 @@ template <> struct NetT<NET_GEN>    { static constexpr int A1 = ACT_RELU,  A2 = 
 template <> struct NetT<NET_DISC>   { static constexpr int A1 = ACT_LRELU, A2 = ACT_LRELU, A3 = ACT_LRELU, A4 = ACT_LINEAR, NT3 = 1, L3 = 20; };
 
 // ---------------------------------------------------------------- LDS carve (floats)
+
 constexpr int PART_FLOATS = 4 * ROWS * 20;           // four waves' 16x16 partial sums of a chained layer
 constexpr int WIDE_FLOATS = ROWS * LD_W;
 constexpr int T3_FLOATS = ROWS * LD_3W;              // h3 tile (16 or 64 columns)
@@ -225,6 +231,9 @@ struct Pre {
     else if constexpr (TMIN > 0) load_first<TMIN>();
   }
 };
+
+// the first layer's fragments of a network of kind KIND
+template <int KIND> using FwdPre = Pre<NT_H, first_groups(KIND)>;
 
 struct NoPre { __device__ __forceinline__ float operator()(int, int) const { return 0.f; } };
 struct NoNext { __device__ __forceinline__ void operator()() const {} };
@@ -468,7 +477,7 @@ template <int KIND> using BwdPre = typename BwdFirst<KIND>::type;
 //   generator (50-wide third layer):      L1 | L2 | L3 + L4 partial sums (chained) | L4 total
 template <int KIND, bool STORE, class X>
 __device__ __forceinline__ void net_forward(const float* __restrict__ wf, const Geo& g, const Tiles& t, const ActsG& ws,
-                                            Pre<NT_H, 2>& p1, X next) {
+                                            FwdPre<KIND>& p1, X next) {
   using N = NetT<KIND>;
   constexpr int L3 = N::L3, NT3 = N::NT3;
   float* h1 = t.h1; float* h2 = t.h2; float* h3 = t.h3; float* out = t.out;

@@ -104,7 +104,7 @@ __device__ __forceinline__ void act_tile(const ActArgs& A, float* smem, int tile
   const long long ptr0 = A.counters ? A.counters[0] : A.pointer;
   const long long step = A.counters ? A.counters[1] : A.step;
 
-  Pre<NT_H, 2> p_a; p_a.issue(A.actor.wf + A.ga.offf[0]);
+  FwdPre<NET_ACTOR> p_a; p_a.issue(A.actor.wf + A.ga.offf[0]);
   sbuf[r * 16 + c] = (valid && c < S) ? A.state[(size_t)gr * S + c] : 0.f;
   // exploration noise of this row: given, drawn here, or none
   float z = 0.f;
@@ -126,7 +126,7 @@ __device__ __forceinline__ void act_tile(const ActArgs& A, float* smem, int tile
   __syncthreads();
   load_x0(t.x0, row0, A.n_env, lin(sbuf, 16, S), nil(), nil(), nullptr);
   __syncthreads();
-  Pre<NT_H, 2> p_g;
+  FwdPre<NET_GEN> p_g;
   net_forward<NET_ACTOR, false>(A.actor.wf, A.ga, t, none, p_a, [&] { p_g.issue(A.gen.wf + A.gg.offf[0]); });   // a = actor.choose_action(s)
   // a = clip(normal(a, var), -1, 1) evaluated in float64 like NumPy (Curious_GAN.py:191)
   if (c < Ad) {
@@ -141,7 +141,7 @@ __device__ __forceinline__ void act_tile(const ActArgs& A, float* smem, int tile
   __syncthreads();
   load_x0(t.x0, row0, A.n_env, lin(sbuf, 16, S), lin(abuf, 16, Ad), nil(), nullptr);
   __syncthreads();
-  Pre<NT_H, 2> p_d;
+  FwdPre<NET_DISC> p_d;
   net_forward<NET_GEN, false>(A.gen.wf, A.gg, t, none, p_g, [&] { p_d.issue(A.disc.wf + A.gd.offf[0]); });   // g = generator.predict(s, a)
   gbuf[r * 16 + c] = c < S ? t.out[r * LD_O + c] : 0.f;
   double s7[7]; uint8_t done = 0;
@@ -238,7 +238,7 @@ __device__ __forceinline__ void eval_d_tile(const EvalArgs& A, float* smem, int 
   const int row0 = tile * ROWS;
   const int S = A.gd.S, Ad = A.gd.A;
   const ActsG none{};
-  Pre<NT_H, 2> p_d; p_d.issue(A.disc.wf + A.gd.offf[0]);
+  FwdPre<NET_DISC> p_d; p_d.issue(A.disc.wf + A.gd.offf[0]);
   float ld = 0.f;
 #pragma unroll 1
   for (int pass = 0; pass < 2; ++pass) {
@@ -260,8 +260,8 @@ __device__ __forceinline__ void eval_g_tile(const EvalArgs& A, float* smem, int 
   const int row0 = tile * ROWS;
   const int S = A.gg.S, Ad = A.gg.A;
   const ActsG none{};
-  Pre<NT_H, 2> p_g; p_g.issue(A.gen.wf + A.gg.offf[0]);
-  Pre<NT_H, 2> p_d;
+  FwdPre<NET_GEN> p_g; p_g.issue(A.gen.wf + A.gg.offf[0]);
+  FwdPre<NET_DISC> p_d;
   if (A.x0g) load_x0_tile(t.x0, A.x0g + (size_t)tile * (ROWS * X0_COLS));
   else load_x0(t.x0, row0, A.n_rows, gin(A.s, S), gin(A.a, Ad), nil(), nullptr);
   __syncthreads();

@@ -19,7 +19,7 @@ __global__ __launch_bounds__(THREADS) void probe_kernel(const Args A) {
   t.part = b; b += PART_FLOATS; t.x0 = b; b += X0_FLOATS; t.h1 = b; b += WIDE_FLOATS; t.h2 = b; b += WIDE_FLOATS;
   t.h3 = b; b += T3_FLOATS; t.out = b;
   const int row0 = blockIdx.x * ROWS;
-  Pre<NT_H, 2> p1; p1.issue(A.wf + A.g.offf[0]);
+  FwdPre<NET_ACTOR> p1; p1.issue(A.wf + A.g.offf[0]);
   STAMP(100);
   load_x0(t.x0, row0, A.n_rows, MatIn{A.s, 7, 7, 0}, MatIn{nullptr, 0, 0, 0}, MatIn{nullptr, 0, 0, 0}, nullptr);
   __syncthreads();
