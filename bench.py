@@ -73,8 +73,20 @@ def cpu_baseline(budget_s=12.0):
         if dt > budget_s or n >= 200:
             break
     threads = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
-    return {"value": round(n / dt, 3), "unit": "updates/s", "cores": threads, "kind": "port",
-            "sample": f"{n} float32 NumPy updates at batch {BATCH} (critic, actor, D, G steps + 2 loss evals), {dt:.1f} s"}
+    out = {"value": round(n / dt, 3), "unit": "updates/s", "cores": threads, "kind": "port",
+           "sample": f"{n} float32 NumPy updates at batch {BATCH} (critic, actor, D, G steps + 2 loss evals), {dt:.1f} s"}
+    try:                                               # the same on one BLAS thread, a few seconds
+        from threadpoolctl import threadpool_limits
+        with threadpool_limits(limits=1):
+            ag.update(batch)
+            n1, t1 = 0, time.perf_counter()
+            while time.perf_counter() - t1 < 4.0:
+                ag.update(batch)
+                n1 += 1
+            out["single_thread_value"] = round(n1 / (time.perf_counter() - t1), 3)
+    except Exception:                                  # threadpoolctl missing or no controllable BLAS: all-core figure only
+        pass
+    return out
 
 
 def main():
