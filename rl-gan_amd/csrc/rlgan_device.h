@@ -30,6 +30,7 @@ constexpr int NP_H = 208;       // padded hidden width (global work arrays)
 constexpr int LD_W = 212;       // wide activation tile (208 columns)
 constexpr int LD_X0 = 36;       // network-input tile (32 columns)
 constexpr int LD_O = 20;        // 16-column tile
+constexpr int LDP = 20;         // row stride of a 16x16 partial-sum tile
 constexpr int LD_3W = 68;       // 64-column tile
 constexpr int X0_COLS = 32;     // global leading dimension of x0 work arrays
 constexpr int ROWS = 16;        // minibatch rows per workgroup
@@ -134,7 +135,9 @@ template <> struct NetT<NET_DISC>   { static constexpr int A1 = ACT_LRELU, A2 = 
 
 // ---------------------------------------------------------------- LDS carve (floats)
 
-constexpr int PART_FLOATS = 4 * ROWS * 20;           // four waves' 16x16 partial sums of a chained layer
+constexpr int CHAIN_SLOTS = 5;                       // partial sums of a chained layer: four waves + the shared tile's k-group
+constexpr int SPART_OFF = CHAIN_SLOTS * ROWS * LDP;  // then four waves' partial sums of a shared tile
+constexpr int PART_FLOATS = (CHAIN_SLOTS + 4) * ROWS * LDP;
 constexpr int WIDE_FLOATS = ROWS * LD_W;
 constexpr int T3_FLOATS = ROWS * LD_3W;              // h3 tile (16 or 64 columns)
 constexpr int X0_FLOATS = ROWS * LD_X0;
@@ -207,9 +210,17 @@ struct FragSrc {
 // that the busier waves of workgroups sharing a compute unit land on different SIMDs.
 // Pre holds the B operands of the first min(GD, NG) k-groups of this wave's tiles: issue() only starts
 // the loads; nothing waits until dense16 consumes them.
+// A wide layer with 4n+1 column tiles (13) would leave one wave a third more MFMAs than the others, and
+// the layer ends when that wave does.  There the last tile is SHARED instead: the other tiles are dealt
+// whole (three each), and of the last tile every wave computes the k-groups w, w+4, w+8, (w+12); the four
+// partial sums meet in LDS (`spart`, slot = rotated wave index, added in slot order) and all threads of
+// the workgroup apply the epilogue to that tile, one element each, behind one more barrier.
 template <int NT, int NG>
 struct Pre {
-  static constexpr int TMAX = (NT + 3) / 4, TMIN = NT / 4, NHEAVY = NT % 4;
+  static constexpr bool SPLIT = (NT % 4 == 1) && NT > 4 && NG >= 8;
+  static constexpr int NTF = SPLIT ? NT - 1 : NT;      // tiles dealt whole
+  static constexpr int NS = SPLIT ? (NG + 3) / 4 : 0;  // k-groups of the shared tile per wave (at most)
+  static constexpr int TMAX = (NTF + 3) / 4, TMIN = NTF / 4, NHEAVY = NTF % 4;
   static constexpr int D = NG < GD ? NG : GD;          // groups in flight
   f32x4 b[D][TMAX];
   FragSrc src;                                         // fragment blocks counted from this wave's tile 0, group 0
@@ -240,8 +251,10 @@ struct NoNext { __device__ __forceinline__ void operator()() const {} };
 
 // The share of one wave in a dense layer: T column tiles over the whole K range.
 template <int NT, int NG, int T, class P, class F, class X>
-__device__ __forceinline__ void dense_tiles(Pre<NT, NG>& p, const float* xq, int r0, int c0, P pre, F f, float* gdst, X next) {
-  constexpr int D = Pre<NT, NG>::D;
+__device__ __forceinline__ void dense_tiles(Pre<NT, NG>& p, const float* xq, int r0, int c0, P pre, F f, float* gdst, X next,
+                                            float* spart) {
+  using Q = Pre<NT, NG>;
+  constexpr int D = Q::D;
   constexpr int KC = (T == 1 && NG >= 4) ? 4 : 1;      // a lone tile splits K over independent accumulation chains
   float hv[T][4];
 #pragma unroll
@@ -258,6 +271,12 @@ __device__ __forceinline__ void dense_tiles(Pre<NT, NG>& p, const float* xq, int
   f32x4 am[D];
 #pragma unroll
   for (int g = 0; g < D; ++g) am[g] = *(const f32x4*)(xq + 16 * g);
+  // this wave's k-groups of the shared tile: fragments requested now, used after the loop
+  f32x4 fs[Q::NS > 0 ? Q::NS : 1];
+  if constexpr (Q::SPLIT) {
+#pragma unroll
+    for (int j = 0; j < Q::NS; ++j) fs[j] = p.src.load(min(p.w + 4 * j, NG - 1) * NT + (NT - 1) - p.w);
+  }
   STAMP(2);
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
@@ -277,9 +296,28 @@ __device__ __forceinline__ void dense_tiles(Pre<NT, NG>& p, const float* xq, int
     // to their consumers to save registers, and the wave would wait out a full L2 round trip per group
     __builtin_amdgcn_sched_barrier(0);
   }
+  f32x4 sz{0.f, 0.f, 0.f, 0.f};
+  if constexpr (Q::SPLIT) {
+    f32x4 as[Q::NS], sacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int j = 0; j < Q::NS; ++j) as[j] = *(const f32x4*)(xq + 16 * min(p.w + 4 * j, NG - 1));
+#pragma unroll
+    for (int j = 0; j < Q::NS; ++j) {
+      if (4 * j + 3 < NG || p.w + 4 * j < NG) {        // only the last j depends on the wave
+#pragma unroll
+        for (int m = 0; m < 4; ++m) sacc[j & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(as[j][m], fs[j][m], sacc[j & 1], 0, 0, 0);
+      }
+    }
+    sz = sacc[0] + sacc[1];
+  }
   STAMP(3);
   next();
   __builtin_amdgcn_sched_barrier(0);   // the next layer's requests stay ahead of this layer's epilogue
+  if constexpr (Q::SPLIT) {
+    float* pw = spart + p.w * (ROWS * LDP) + r0 * LDP + c0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) pw[r * LDP] = sz[r];
+  }
 #pragma unroll
   for (int i = 0; i < T; ++i) {
     const int col = 16 * (p.w + 4 * i) + c0;
@@ -341,22 +379,38 @@ __device__ __forceinline__ void dense16_rega(Pre<NT, 1>& p, const f32x4 a, P pre
 // order) with the matching k-groups of the narrow layer's weights, and leaves a 16x16 partial sum in
 // `part`; the workgroup barrier that ends the wide layer then covers both, and whoever needs the
 // narrow layer's output adds the four partial sums in wave order.
-constexpr int LDP = 20;                               // row stride of a partial-sum tile
 struct NoChain {
   static constexpr bool active = false;
   template <int T> __device__ __forceinline__ void run(int, const float*, int) const {}
 };
-template <int TMAX>
+// LAST: the wide layer's last tile is shared between the waves (Pre::SPLIT), so nobody owns it; the
+// narrow layer's last k-group is then added separately once that tile is complete (`wlast` holds its
+// fragments): run_last() into a fifth slot, or operand-swapped in registers where the consumer wants that.
+template <int TMAX, bool LAST = false>
 struct Chain {
   static constexpr bool active = true;
   f32x4 wc[TMAX];                                      // narrow layer's fragments of the k-groups w, w+4, ...
-  float* part;                                         // [4 waves][16][LDP]
+  f32x4 wlast;                                         // ... and of its last k-group (LAST only)
+  float* part;                                         // [CHAIN_SLOTS][16][LDP]
   // wn: fragment image of the narrow layer (one column tile); ng: its number of k-groups
   __device__ __forceinline__ void issue(const float* __restrict__ wn, int ng, int w) {
     FragSrc src;
     src.set(wn, 0);
 #pragma unroll
     for (int i = 0; i < TMAX; ++i) wc[i] = src.load(min(w + 4 * i, ng - 1));
+    if constexpr (LAST) wlast = src.load(ng - 1);
+  }
+  // the last k-group's product from the completed tile at column 16*(ng-1) of xs, into slot 4 (one wave calls this)
+  __device__ __forceinline__ void run_last(const float* xs, int ldx, int ng) {
+    const int lane = threadIdx.x & 63;
+    const int r0 = (lane >> 4) * 4, c0 = lane & 15;
+    const f32x4 a = *(const f32x4*)(xs + c0 * ldx + r0 + 16 * (ng - 1));
+    f32x4 acc{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int m = 0; m < 4; ++m) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], wlast[m], acc, 0, 0, 0);
+    float* pw = part + 4 * (ROWS * LDP) + r0 * LDP + c0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) pw[r * LDP] = acc[r];
   }
   // xs: the wide layer's output tile in LDS (row stride ldx); this wave owns its column tiles w, w+4, ...
   template <int T>
@@ -389,6 +443,9 @@ __device__ __forceinline__ float chain_sum1(const float* part, int row, int col)
   constexpr int WS = ROWS * LDP;
   return ((q[0] + q[WS]) + q[2 * WS]) + q[3 * WS];
 }
+__device__ __forceinline__ float chain_sum1_last(const float* part, int row, int col) {   // with run_last()'s slot
+  return chain_sum1(part, row, col) + part[4 * (ROWS * LDP) + row * LDP + col];
+}
 
 // One dense layer of a 16-row tile, Z[16, NT*16] = X[16, NG*16] * fragments.
 //   p     the layer's weight fragments, already requested with p.issue()
@@ -404,21 +461,22 @@ __device__ __forceinline__ float chain_sum1(const float* part, int row, int col)
 // Ends with a workgroup barrier on LDS (what the epilogues wrote is visible to every wave after it).
 template <int NT, int NG, class P, class F, class X, class CH>
 __device__ __forceinline__ void dense16(Pre<NT, NG>& p, const float* xs, int ldx, P pre, F f, float* gdst, X next,
-                                        CH& chain, const float* ys, int ldy) {
+                                        CH& chain, const float* ys, int ldy, float* spart = nullptr) {
   using Q = Pre<NT, NG>;
   const int lane = threadIdx.x & 63;
   const int r0 = (lane >> 4) * 4, c0 = lane & 15;
   const float* xq = xs + c0 * ldx + r0;                 // A operands of a group: one float4 at xq + 16*group
   STAMP(1);
   if constexpr (Q::NHEAVY == 0) {
-    dense_tiles<NT, NG, Q::TMAX>(p, xq, r0, c0, pre, f, gdst, next);
+    dense_tiles<NT, NG, Q::TMAX>(p, xq, r0, c0, pre, f, gdst, next, spart);
     if constexpr (CH::active) chain.template run<Q::TMAX>(p.w, ys, ldy);
   } else {
+    static_assert(!Q::SPLIT, "a shared tile leaves the whole tiles evenly dealt");
     if (p.w < Q::NHEAVY) {
-      dense_tiles<NT, NG, Q::TMAX>(p, xq, r0, c0, pre, f, gdst, next);
+      dense_tiles<NT, NG, Q::TMAX>(p, xq, r0, c0, pre, f, gdst, next, spart);
       if constexpr (CH::active) chain.template run<Q::TMAX>(p.w, ys, ldy);
     } else if constexpr (Q::TMIN > 0) {
-      dense_tiles<NT, NG, Q::TMIN>(p, xq, r0, c0, pre, f, gdst, next);
+      dense_tiles<NT, NG, Q::TMIN>(p, xq, r0, c0, pre, f, gdst, next, spart);
       if constexpr (CH::active) chain.template run<Q::TMIN>(p.w, ys, ldy);
     } else {
       next();
@@ -427,12 +485,23 @@ __device__ __forceinline__ void dense16(Pre<NT, NG>& p, const float* xs, int ldx
   }
   STAMP(4);
   lds_barrier();
+  if constexpr (Q::SPLIT) {
+    // the shared tile: four partial sums in slot order, epilogue, one element per thread
+    const int r = threadIdx.x >> 4, c = threadIdx.x & 15, col = 16 * (NT - 1) + c;
+    const float* q = spart + r * LDP + c;
+    constexpr int WS = ROWS * LDP;
+    const float z = ((q[0] + q[WS]) + q[2 * WS]) + q[3 * WS];
+    const float v = f(r, col, z, pre(r, col));
+    if (gdst) gdst[work_off(NT * 16, r, col)] = v;
+    lds_barrier();
+  }
   STAMP(5);
 }
 template <int NT, int NG, class P, class F, class X>
-__device__ __forceinline__ void dense16(Pre<NT, NG>& p, const float* xs, int ldx, P pre, F f, float* gdst, X next) {
+__device__ __forceinline__ void dense16(Pre<NT, NG>& p, const float* xs, int ldx, P pre, F f, float* gdst, X next,
+                                        float* spart = nullptr) {
   NoChain nc;
-  dense16(p, xs, ldx, pre, f, gdst, next, nc, nullptr, 0);
+  dense16(p, xs, ldx, pre, f, gdst, next, nc, nullptr, 0, spart);
 }
 
 // the fragments of a one-tile layer (NG k-groups), loaded by EVERY wave: for layers so small that each
@@ -495,17 +564,27 @@ __device__ __forceinline__ void net_forward(const float* __restrict__ wf, const 
     return v;
   };
   if constexpr (NT3 == 1) {
-    Chain<Pre<NT_H, NT_H>::TMAX> ch;
+    using Q2 = Pre<NT_H, NT_H>;
+    Chain<Q2::TMAX, Q2::SPLIT> ch;
     ch.part = t.part;
     PreAll<1> p4;
     dense16(p2, h1, LD_W, NoPre{}, f2, STORE ? ws.h2 : nullptr,
-            [&] { ch.issue(wf + g.offf[2], NT_H, p2.w); p4.issue(wf + g.offf[3]); }, ch, h2, LD_W);
+            [&] { ch.issue(wf + g.offf[2], NT_H, p2.w); p4.issue(wf + g.offf[3]); }, ch, h2, LD_W, t.part + SPART_OFF);
     next();
     if (wave_id() == 0) {
       // third layer: total of the partial sums, activation; the lane holds row l&15, columns 4q..4q+3,
       // which is the A operand of the fourth layer
       const int row = lane & 15, k0 = (lane >> 4) * 4;
-      const f32x4 s = chain_sum4(t.part, row, k0);
+      f32x4 s = chain_sum4(t.part, row, k0);
+      if constexpr (Q2::SPLIT) {
+        // the last k-group (the shared tile of h2, complete since the layer's second barrier): operands
+        // swapped, so the product arrives in this lane's (row, four columns) layout
+        const f32x4 hb = *(const f32x4*)(h2 + row * LD_W + 16 * (NT_H - 1) + k0);
+        f32x4 e{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int m = 0; m < 4; ++m) e = __builtin_amdgcn_mfma_f32_16x16x4f32(ch.wlast[m], hb[m], e, 0, 0, 0);
+        s += e;
+      }
       f32x4 v;
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = k0 + r < n3 ? act_f<N::A3>(s[r]) : (k0 + r == n3 ? 1.f : 0.f);
@@ -524,7 +603,7 @@ __device__ __forceinline__ void net_forward(const float* __restrict__ wf, const 
     lds_barrier();
   } else {
     Pre<NT3, NT_H> p3;
-    dense16(p2, h1, LD_W, NoPre{}, f2, STORE ? ws.h2 : nullptr, [&] { p3.issue(wf + g.offf[2]); });
+    dense16(p2, h1, LD_W, NoPre{}, f2, STORE ? ws.h2 : nullptr, [&] { p3.issue(wf + g.offf[2]); }, t.part + SPART_OFF);
     Chain<1> ch;
     ch.part = t.part;
     dense16(p3, h2, LD_W, NoPre{}, [=](int r, int c, float z, float) {
@@ -601,17 +680,23 @@ __device__ __forceinline__ void net_backward(const float* __restrict__ wb, const
   };
   auto g1 = [=](int r, int c) { return h1[r * LD_W + c]; };
   if constexpr (NEED_DX0) {
-    Chain<Pre<NT_H, NT_H>::TMAX> ch;
+    using Q2 = Pre<NT_H, NT_H>;
+    Chain<Q2::TMAX, Q2::SPLIT> ch;
     ch.part = t.part;
-    dense16(p2, h2, LD_W, g1, f1, STORE ? ws.dz1 : nullptr, [&] { ch.issue(wb + g.offb[0], NT_H, p2.w); }, ch, h1, LD_W);
+    dense16(p2, h2, LD_W, g1, f1, STORE ? ws.dz1 : nullptr, [&] { ch.issue(wb + g.offb[0], NT_H, p2.w); }, ch, h1, LD_W,
+            t.part + SPART_OFF);
     next();
+    if constexpr (Q2::SPLIT) {
+      if (wave_id() == 0) ch.run_last(h1, LD_W, NT_H);      // dz1's shared tile times the last k-group of W1^T
+      lds_barrier();
+    }
     {
       const int r = threadIdx.x >> 4, c = threadIdx.x & 15;
-      x0[r * LD_X0 + c] = chain_sum1(t.part, r, c);
+      x0[r * LD_X0 + c] = Q2::SPLIT ? chain_sum1_last(t.part, r, c) : chain_sum1(t.part, r, c);
     }
     lds_barrier();
   } else {
-    dense16(p2, h2, LD_W, g1, f1, STORE ? ws.dz1 : nullptr, next);
+    dense16(p2, h2, LD_W, g1, f1, STORE ? ws.dz1 : nullptr, next, t.part + SPART_OFF);
   }
 }
 

@@ -11,7 +11,7 @@ constexpr int ITER = 16;
 template <int NG>
 __global__ __launch_bounds__(THREADS) void ks(const float* __restrict__ w, float* out, int pad) {
   extern __shared__ float dyn[];
-  __shared__ __attribute__((aligned(16))) float h1[WIDE_FLOATS], h2[WIDE_FLOATS];
+  __shared__ __attribute__((aligned(16))) float h1[WIDE_FLOATS], h2[WIDE_FLOATS], sp[4 * ROWS * LDP];
   for (int i = threadIdx.x; i < WIDE_FLOATS; i += THREADS) { h1[i] = 0.001f * (i % 13); h2[i] = 0.f; }
   __syncthreads();
   Pre<NT_H, NG> p;
@@ -23,7 +23,7 @@ __global__ __launch_bounds__(THREADS) void ks(const float* __restrict__ w, float
       const float v = c < HID ? act_f<ACT_RELU6>(z) : (c == HID ? 1.f : 0.f);
       dst[r * LD_W + c] = v;
       return v;
-    }, nullptr, [&] { p.issue(w); });
+    }, nullptr, [&] { p.issue(w); }, sp);
     float* t = a; a = b; b = t;
   }
   if (a[threadIdx.x] == 12345.678f) out[threadIdx.x] = a[threadIdx.x + 1] + dyn[pad & 1];
@@ -31,7 +31,7 @@ __global__ __launch_bounds__(THREADS) void ks(const float* __restrict__ w, float
 
 __global__ __launch_bounds__(THREADS) void k(const float* __restrict__ w, float* out, int pad) {
   extern __shared__ float dyn[];
-  __shared__ __attribute__((aligned(16))) float h1[WIDE_FLOATS], h2[WIDE_FLOATS];
+  __shared__ __attribute__((aligned(16))) float h1[WIDE_FLOATS], h2[WIDE_FLOATS], sp[4 * ROWS * LDP];
   for (int i = threadIdx.x; i < WIDE_FLOATS; i += THREADS) { h1[i] = 0.001f * (i % 13); h2[i] = 0.f; }
   __syncthreads();
   Pre<NT_H, NT_H> p;
@@ -43,7 +43,7 @@ __global__ __launch_bounds__(THREADS) void k(const float* __restrict__ w, float*
       const float v = c < HID ? act_f<ACT_RELU6>(z) : (c == HID ? 1.f : 0.f);
       dst[r * LD_W + c] = v;
       return v;
-    }, nullptr, [&] { p.issue(w); });
+    }, nullptr, [&] { p.issue(w); }, sp);
     float* t = a; a = b; b = t;
   }
   if (a[threadIdx.x] == 12345.678f) out[threadIdx.x] = a[threadIdx.x + 1] + dyn[pad & 1];
