@@ -39,14 +39,14 @@ __device__ __forceinline__ void critic_tile(const CriticArgs& A, float* smem, in
   // target action a' = actor_target(s')
   FwdPre<NET_ACTOR> p_at; p_at.issue(A.actor_t.wf + A.ga.offf[0]);
   stage_rows(stage, row0, A.n_rows, gin(A.s, S), gin(A.a, Ad), gin(A.r, 1), gin(A.s_next, S));
-  __syncthreads();
+  lds_barrier();
   load_x0(t.x0, row0, A.n_rows, lin(st_sn, STAGE_LD, S), nil(), nil(), nullptr);
-  __syncthreads();
+  lds_barrier();
   FwdPre<NET_CRITIC> p_ct;
   net_forward<NET_ACTOR, false>(A.actor_t.wf, A.ga, t, none, p_at, [&] { p_ct.issue(A.critic_t.wf + A.gc.offf[0]); });
   // q' = critic_target(s', a')
   load_x0(t.x0, row0, A.n_rows, lin(st_sn, STAGE_LD, S), lin(t.out, LD_O, Ad), nil(), nullptr);
-  __syncthreads();
+  lds_barrier();
   FwdPre<NET_CRITIC> p_ce;
   net_forward<NET_CRITIC, false>(A.critic_t.wf, A.gc, t, none, p_ct, [&] { p_ce.issue(A.critic_e.wf + A.gc.offf[0]); });
   if (threadIdx.x < ROWS) {
@@ -56,7 +56,7 @@ __device__ __forceinline__ void critic_tile(const CriticArgs& A, float* smem, in
   // q = critic_eval(s, a)
   const ActsG wc = acts_at(A.acts_c.p, row0, A.gc.ld3);
   load_x0(t.x0, row0, A.n_rows, lin(st_s, STAGE_LD, S), lin(st_a, STAGE_LD, Ad), nil(), wc.x0);
-  __syncthreads();
+  lds_barrier();
   PreAll<1> p_cb;
   net_forward<NET_CRITIC, true>(A.critic_e.wf, A.gc, t, wc, p_ce, [&] { p_cb.issue(A.critic_e.wb + A.gc.offb[3]); });
   float l = 0.f;
@@ -69,7 +69,7 @@ __device__ __forceinline__ void critic_tile(const CriticArgs& A, float* smem, in
   const float lsum = sum16_lds(small + 32, l);
   if (threadIdx.x == 0) A.loss_parts[tile] = lsum;
   fill_out_col0(t.out, small + 16);
-  __syncthreads();
+  lds_barrier();
   if (A.train_actor) {
     FwdPre<NET_ACTOR> p_ae;
     net_backward<NET_CRITIC, true, true>(A.critic_e.wb, A.gc, t, wc, p_cb, [&] { p_ae.issue(A.actor_e.wf + A.ga.offf[0]); });
@@ -84,17 +84,17 @@ __device__ __forceinline__ void critic_tile(const CriticArgs& A, float* smem, in
       }
       dsave[r * LD_O + c] = v;
     }
-    __syncthreads();
+    lds_barrier();
     const ActsG wa = acts_at(A.acts_a.p, row0, A.ga.ld3);
     load_x0(t.x0, row0, A.n_rows, lin(st_s, STAGE_LD, S), nil(), nil(), wa.x0);
-    __syncthreads();
+    lds_barrier();
     PreAll<1> p_ab;
     net_forward<NET_ACTOR, true>(A.actor_e.wf, A.ga, t, wa, p_ae, [&] { p_ab.issue(A.actor_e.wb + A.ga.offb[3]); });
     {
       const int r = threadIdx.x >> 4, c = threadIdx.x & 15;
       t.out[r * LD_O + c] = dsave[r * LD_O + c];
     }
-    __syncthreads();
+    lds_barrier();
     net_backward<NET_ACTOR, false, true>(A.actor_e.wb, A.ga, t, wa, p_ab, NoNext{});
   } else {
     net_backward<NET_CRITIC, false, true>(A.critic_e.wb, A.gc, t, wc, p_cb, NoNext{});
@@ -132,18 +132,18 @@ __device__ __forceinline__ void actor_tile(const ActorArgs& A, float* smem, int 
 
   FwdPre<NET_ACTOR> p_a; p_a.issue(A.actor_e.wf + A.ga.offf[0]);
   load_x0(ta.x0, row0, A.n_rows, gin(A.s, S), nil(), nil(), wa.x0);
-  __syncthreads();
+  lds_barrier();
   FwdPre<NET_CRITIC> p_c;
   net_forward<NET_ACTOR, true>(A.actor_e.wf, A.ga, ta, wa, p_a, [&] { p_c.issue(A.critic_e.wf + A.gc.offf[0]); });   // a = actor_eval(s), live
   load_x0(tc.x0, row0, A.n_rows, lin(ta.x0, LD_X0, S), lin(ta.out, LD_O, Ad), nil(), nullptr);   // s: from the actor's input tile
-  __syncthreads();
+  lds_barrier();
   PreAll<1> p_cb;
   net_forward<NET_CRITIC, false>(A.critic_e.wf, A.gc, tc, none, p_c, [&] { p_cb.issue(A.critic_e.wb + A.gc.offb[3]); });
   {
     const int r = threadIdx.x >> 4, c = threadIdx.x & 15;
     tc.out[r * LD_O + c] = (c == 0 && row0 + r < A.n_rows) ? 1.f : 0.f;   // d(sum_b q_b)/dq = 1, DDPG.py:151
   }
-  __syncthreads();
+  lds_barrier();
   PreAll<1> p_ab;
   net_backward<NET_CRITIC, true, false>(A.critic_e.wb, A.gc, tc, none, p_cb, [&] { p_ab.issue(A.actor_e.wb + A.ga.offb[3]); });
   {
@@ -155,7 +155,7 @@ __device__ __forceinline__ void actor_tile(const ActorArgs& A, float* smem, int 
     }
     ta.out[r * LD_O + c] = v;
   }
-  __syncthreads();
+  lds_barrier();
   net_backward<NET_ACTOR, false, true>(A.actor_e.wb, A.ga, ta, wa, p_ab, NoNext{});
 }
 
@@ -191,13 +191,13 @@ __device__ __forceinline__ void disc_tile(const DiscArgs& A, float* smem, int ti
   float ltot = 0.f;
   FwdPre<NET_DISC> p_f; p_f.issue(A.disc.wf + A.gd.offf[0]);
   stage_rows(stage, row0, A.n_rows, gin(A.s, S), gin(A.g, S), gin(A.a, Ad), gin(A.s_next, S));
-  __syncthreads();
+  lds_barrier();
 #pragma unroll 1
   for (int pass = 0; pass < 2; ++pass) {
     const ActsG wd = acts_at(A.acts_d.p, pass * A.rows16 + row0, A.gd.ld3);
     load_x0(t.x0, row0, A.n_rows, lin(stage, STAGE_LD, S), lin(stage + (pass == 0 ? S : 2 * S + Ad), STAGE_LD, S),
             lin(stage + 2 * S, STAGE_LD, Ad), wd.x0);
-    __syncthreads();
+    lds_barrier();
     PreAll<1> p_b;
     net_forward<NET_DISC, true>(A.disc.wf, A.gd, t, wd, p_f, [&] { p_b.issue(A.disc.wb + A.gd.offb[3]); });
     const float label = pass == 0 ? 0.f : A.label_real;
@@ -210,7 +210,7 @@ __device__ __forceinline__ void disc_tile(const DiscArgs& A, float* smem, int ti
     }
     ltot += sum16_lds(small + 16, l);
     fill_out_col0(t.out, small);
-    __syncthreads();
+    lds_barrier();
     net_backward<NET_DISC, false, true>(A.disc.wb, A.gd, t, wd, p_b, [&] { p_f.issue(A.disc.wf + A.gd.offf[0]); });
   }
   if (threadIdx.x == 0) A.loss_parts[tile] = ltot;
@@ -250,11 +250,11 @@ __device__ __forceinline__ void gen_tile(const GenArgs& A, float* smem, int tile
 
   FwdPre<NET_GEN> p_g; p_g.issue(A.gen.wf + A.gg.offf[0]);
   load_x0(tg.x0, row0, A.n_rows, gin(A.s, S), gin(A.a, Ad), nil(), wg.x0);
-  __syncthreads();
+  lds_barrier();
   FwdPre<NET_DISC> p_d;
   net_forward<NET_GEN, true>(A.gen.wf, A.gg, tg, wg, p_g, [&] { p_d.issue(A.disc.wf + A.gd.offf[0]); });   // g^ = G(s, a), live
   load_x0(td.x0, row0, A.n_rows, lin(tg.x0, LD_X0, S), lin(tg.out, LD_O, S), lin(tg.x0 + S, LD_X0, Ad), nullptr);   // s, a: from G's input tile
-  __syncthreads();
+  lds_barrier();
   PreAll<1> p_db;
   net_forward<NET_DISC, false>(A.disc.wf, A.gd, td, none, p_d, [&] { p_db.issue(A.disc.wb + A.gd.offb[3]); });
   float l = 0.f;
@@ -267,14 +267,14 @@ __device__ __forceinline__ void gen_tile(const GenArgs& A, float* smem, int tile
   const float lsum = sum16_lds(small + 16, l);
   if (threadIdx.x == 0) A.loss_parts[tile] = lsum;
   fill_out_col0(td.out, small);
-  __syncthreads();
+  lds_barrier();
   Pre<4, 1> p_gb;
   net_backward<NET_DISC, true, false>(A.disc.wb, A.gd, td, none, p_db, [&] { p_gb.issue(A.gen.wb + A.gg.offb[3]); });   // dX only
   {
     const int r = threadIdx.x >> 4, c = threadIdx.x & 15;
     tg.out[r * LD_O + c] = c < S ? td.x0[r * LD_X0 + S + c] : 0.f;      // dL/dg^ (linear output layer)
   }
-  __syncthreads();
+  lds_barrier();
   net_backward<NET_GEN, false, true>(A.gen.wb, A.gg, tg, wg, p_gb, NoNext{});
 }
 
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(THREADS) void mlp_forward_kernel(const FwdArgs A) {
   if (KIND == NET_ACTOR) load_x0(t.x0, row0, A.n_rows, gin(A.s, S), nil(), nil(), nullptr);
   else if (KIND == NET_DISC) load_x0(t.x0, row0, A.n_rows, gin(A.s, S), gin(A.x, S), gin(A.a, Ad), nullptr);
   else load_x0(t.x0, row0, A.n_rows, gin(A.s, S), gin(A.a, Ad), nil(), nullptr);
-  __syncthreads();
+  lds_barrier();
   net_forward<KIND, false>(A.net.wf, A.g, t, none, p1, NoNext{});
   const int r = threadIdx.x >> 4, c = threadIdx.x & 15;
   if (row0 + r < A.n_rows && c < A.g.NOUT) {

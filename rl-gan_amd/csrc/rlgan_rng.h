@@ -67,7 +67,7 @@ __device__ __forceinline__ void mt_choice_body(uint32_t* state, uint32_t rng, ui
   const int tid = threadIdx.x;
   for (int i = tid; i < MT_N; i += NTH) mt[i] = state[i];
   if (tid == 0) { ctl[0] = (int)state[MT_N]; ctl[1] = 0; ctl[2] = -1; }
-  __syncthreads();
+  lds_barrier();
   if (rng == 0) {   // population of one: zeros, no draws consumed
     for (int i = tid; i < n; i += NTH) out[i] = 0;
     return;
@@ -79,18 +79,18 @@ __device__ __forceinline__ void mt_choice_body(uint32_t* state, uint32_t rng, ui
       // new[i] = new/old[(i+397)%624] ^ mix(old[i], old[i+1]); phase bounds follow the data dependences
       uint32_t v = 0;
       if (tid < 227) v = mt[tid + MT_M] ^ mt_mix(mt[tid], mt[tid + 1]);
-      __syncthreads();
+      lds_barrier();
       if (tid < 227) mt[tid] = v;
-      __syncthreads();
+      lds_barrier();
       if (tid < 227) v = mt[tid] ^ mt_mix(mt[tid + 227], mt[tid + 228]);
-      __syncthreads();
+      lds_barrier();
       if (tid < 227) mt[tid + 227] = v;
-      __syncthreads();
+      lds_barrier();
       if (tid < 169) v = mt[tid + 227] ^ mt_mix(mt[tid + 454], mt[tid + 455]);
       if (tid == 169) v = mt[396] ^ mt_mix(mt[623], mt[0]);
-      __syncthreads();
+      lds_barrier();
       if (tid < 170) mt[tid + 454] = v;
-      __syncthreads();
+      lds_barrier();
       pos = 0;
     }
     const int j = pos + tid;
@@ -101,19 +101,19 @@ __device__ __forceinline__ void mt_choice_body(uint32_t* state, uint32_t rng, ui
     const int lane = tid & 63, wave = tid >> 6;
     const int before = __popcll(bal & ((1ull << lane) - 1ull));
     if (lane == 0) wave_cnt[wave] = __popcll(bal);
-    __syncthreads();
+    lds_barrier();
     int base = 0, total = 0;
 #pragma unroll
     for (int w = 0; w < NTH / 64; ++w) { const int cw = wave_cnt[w]; if (w < wave) base += cw; total += cw; }
     const int rank = count + base + before;
     if (acc && rank < n) out[rank] = (long long)val;
     if (acc && rank == n - 1) ctl[2] = j + 1;       // stream position right after the last draw used
-    __syncthreads();
+    lds_barrier();
     if (tid == 0) {
       if (count + total >= n) { ctl[1] = n; ctl[0] = ctl[2]; }
       else { ctl[1] = count + total; ctl[0] = min(pos + NTH, MT_N); }
     }
-    __syncthreads();
+    lds_barrier();
   }
   for (int i = tid; i < MT_N; i += NTH) state[i] = mt[i];
   if (tid == 0) state[MT_N] = (uint32_t)ctl[0];

@@ -56,13 +56,13 @@ __device__ __forceinline__ TileSet carve_set(float* base) {
 // sum of v over the first 16 threads' values, returned to thread 0 (deterministic order)
 __device__ __forceinline__ float sum16_lds(float* scratch16, float v) {
   if (threadIdx.x < ROWS) scratch16[threadIdx.x] = v;
-  __syncthreads();
+  lds_barrier();
   float s = 0.f;
   if (threadIdx.x == 0) {
 #pragma unroll
     for (int i = 0; i < ROWS; ++i) s += scratch16[i];
   }
-  __syncthreads();
+  lds_barrier();
   return s;
 }
 

@@ -123,9 +123,9 @@ __device__ __forceinline__ void act_tile(const ActArgs& A, float* smem, int tile
     A.counters_out[0] = p; A.counters_out[1] = step + 1;
     if (A.var_out) A.var_out[0] = (A.var_decay > 0.0 && p > A.capacity) ? fmax(var * A.var_decay, A.var_min) : var;
   }
-  __syncthreads();
+  lds_barrier();
   load_x0(t.x0, row0, A.n_env, lin(sbuf, 16, S), nil(), nil(), nullptr);
-  __syncthreads();
+  lds_barrier();
   FwdPre<NET_GEN> p_g;
   net_forward<NET_ACTOR, false>(A.actor.wf, A.ga, t, none, p_a, [&] { p_g.issue(A.gen.wf + A.gg.offf[0]); });   // a = actor.choose_action(s)
   // a = clip(normal(a, var), -1, 1) evaluated in float64 like NumPy (Curious_GAN.py:191)
@@ -138,9 +138,9 @@ __device__ __forceinline__ void act_tile(const ActArgs& A, float* smem, int tile
   } else {
     abuf[r * 16 + c] = 0.f;
   }
-  __syncthreads();
+  lds_barrier();
   load_x0(t.x0, row0, A.n_env, lin(sbuf, 16, S), lin(abuf, 16, Ad), nil(), nullptr);
-  __syncthreads();
+  lds_barrier();
   FwdPre<NET_DISC> p_d;
   net_forward<NET_GEN, false>(A.gen.wf, A.gg, t, none, p_g, [&] { p_d.issue(A.disc.wf + A.gd.offf[0]); });   // g = generator.predict(s, a)
   gbuf[r * 16 + c] = c < S ? t.out[r * LD_O + c] : 0.f;
@@ -155,13 +155,13 @@ __device__ __forceinline__ void act_tile(const ActArgs& A, float* smem, int tile
     if (A.reward_out) A.reward_out[ei] = rew;
     if (A.done_out) A.done_out[ei] = done;
   }
-  __syncthreads();
+  lds_barrier();
   load_x0(t.x0, row0, A.n_env, lin(sbuf, 16, S), lin(gbuf, 16, S), lin(abuf, 16, Ad), nullptr);
-  __syncthreads();
+  lds_barrier();
   net_forward<NET_DISC, false>(A.disc.wf, A.gd, t, none, p_d, NoNext{});
   if (threadIdx.x < ROWS)                                                  // curious_r = r + ITA*(1 - D_fake)
     rbuf[threadIdx.x * 2 + 1] = rbuf[threadIdx.x * 2] + A.ita * (1.f - sigmoid_f(t.out[threadIdx.x * LD_O]));
-  __syncthreads();
+  lds_barrier();
   // M.store_transition(s, s_, g, a, r, curious_r)  (Curious_GAN.py:161-165,195)
   for (int e = threadIdx.x; e < ROWS * 32; e += THREADS) {
     const int rr = e >> 5, cc = e & 31;
@@ -244,7 +244,7 @@ __device__ __forceinline__ void eval_d_tile(const EvalArgs& A, float* smem, int 
   for (int pass = 0; pass < 2; ++pass) {
     if (A.x0d) load_x0_tile(td.x0, A.x0d + (size_t)(pass * A.n_tiles + tile) * (ROWS * X0_COLS));
     else load_x0(td.x0, row0, A.n_rows, gin(A.s, S), gin(pass == 0 ? A.g : A.s_next, S), gin(A.a, Ad), nullptr);
-    __syncthreads();
+    lds_barrier();
     net_forward<NET_DISC, false>(A.disc.wf, A.gd, td, none, p_d, [&] { p_d.issue(A.disc.wf + A.gd.offf[0]); });
     float l = 0.f;
     if (threadIdx.x < ROWS && row0 + threadIdx.x < A.n_rows) l = sigmoid_ce(td.out[threadIdx.x * LD_O], pass == 0 ? 0.f : A.label_real);
@@ -264,7 +264,7 @@ __device__ __forceinline__ void eval_g_tile(const EvalArgs& A, float* smem, int 
   FwdPre<NET_DISC> p_d;
   if (A.x0g) load_x0_tile(t.x0, A.x0g + (size_t)tile * (ROWS * X0_COLS));
   else load_x0(t.x0, row0, A.n_rows, gin(A.s, S), gin(A.a, Ad), nil(), nullptr);
-  __syncthreads();
+  lds_barrier();
   net_forward<NET_GEN, false>(A.gen.wf, A.gg, t, none, p_g, [&] { p_d.issue(A.disc.wf + A.gd.offf[0]); });
   // the generated state moves out of t.out before the discriminator's forward pass reuses the tiles
   float* gsave = t.h3;                                   // free until the discriminator's third layer; x0 is built first
@@ -272,17 +272,17 @@ __device__ __forceinline__ void eval_g_tile(const EvalArgs& A, float* smem, int 
     const int r = threadIdx.x >> 4, c = threadIdx.x & 15;
     gsave[r * 16 + c] = t.out[r * LD_O + c];
   }
-  __syncthreads();
+  lds_barrier();
   if (A.x0d) {
     // [s, x, a, 1] of the fake rows with x replaced by the generated state (zero rows beyond the batch)
     load_x0_tile(t.x0, A.x0d + (size_t)tile * (ROWS * X0_COLS));
-    __syncthreads();
+    lds_barrier();
     const int r = threadIdx.x >> 4, c = threadIdx.x & 15;
     if (c < S) t.x0[r * LD_X0 + S + c] = row0 + r < A.n_rows ? gsave[r * 16 + c] : 0.f;
   } else {
     load_x0(t.x0, row0, A.n_rows, gin(A.s, S), lin(gsave, 16, S), gin(A.a, Ad), nullptr);
   }
-  __syncthreads();
+  lds_barrier();
   net_forward<NET_DISC, false>(A.disc.wf, A.gd, t, none, p_d, NoNext{});
   float l = 0.f;
   if (threadIdx.x < ROWS && row0 + threadIdx.x < A.n_rows) l = sigmoid_ce(t.out[threadIdx.x * LD_O], 1.f);
