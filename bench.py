@@ -96,6 +96,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="launch kernels one by one instead of replaying a HIP graph")
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling: 4096 environments and a global batch of 4096 split over the ranks (default: 4096 each per GPU)")
     args = ap.parse_args()
 
     import torch
@@ -109,7 +111,9 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     import rl_gan_amd as R
-    cfg = R.LearnerConfig(n_env=N_ENV, batch_size=BATCH, memory_capacity=CAPACITY, seed=1)
+    n_env, batch = (N_ENV // world, BATCH // world) if args.strong else (N_ENV, BATCH)
+    assert n_env * world == N_ENV or not args.strong, "--strong needs a rank count that divides 4096"
+    cfg = R.LearnerConfig(n_env=n_env, batch_size=batch, memory_capacity=CAPACITY, seed=1)
     L = R.CuriousLearner(cfg)
     L.fill()                                            # 257 acting steps: the ring must be full before learning
     launch = "eager"
@@ -153,15 +157,15 @@ def main():
         # median over the eager pass: robust against the first launches (lazy work-array setup)
         avg_ms = {k: sorted(v)[len(v) // 2] for k, v in times.items()}
         dom = max(avg_ms, key=avg_ms.get)
-        flop = 2.0 * MACS_PER_ROW[dom] * BATCH
+        flop = 2.0 * MACS_PER_ROW[dom] * batch
         achieved = flop / (avg_ms[dom] * 1e-3) / 1e12
         out = {
-            "metric": "learner updates/sec (batch 4096)", "value": round(world * args.steps / dt, 2), "unit": "updates/s",
+            "metric": "learner updates/sec (batch 4096)", "value": round((1 if args.strong else world) * args.steps / dt, 2), "unit": "updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "curious_gan_ddpg_arm_b4096", "envs_per_gpu": N_ENV, "batch_per_gpu": BATCH,
-                       "replay_rows_per_gpu": CAPACITY, "global_batch": BATCH * world, "parallelism": f"dp{world}", "launch": launch},
-            "env_steps_per_s": round(world * N_ENV * args.steps / dt, 1),
+            "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "curious_gan_ddpg_arm_b4096", "envs_per_gpu": n_env, "batch_per_gpu": batch,
+                       "replay_rows_per_gpu": CAPACITY, "global_batch": batch * world, "parallelism": f"dp{world}", "launch": launch},
+            "env_steps_per_s": round(world * n_env * args.steps / dt, 1),
             "kernel_ms": {k: round(v, 4) for k, v in sorted(avg_ms.items())},
             "losses": {k: round(v, 6) for k, v in losses.items()},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 3), "peak": PEAK_FP32_TFLOPS,
