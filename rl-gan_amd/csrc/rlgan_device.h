@@ -102,7 +102,7 @@ __host__ __device__ inline int work_off(int ld, int r, int c) { return (r >> 2) 
 // ---------------------------------------------------------------- activations
 template <int ACT> __device__ __forceinline__ float act_f(float z) {
   if (ACT == ACT_RELU)  return fmaxf(z, 0.f);
-  if (ACT == ACT_RELU6) return fminf(fmaxf(z, 0.f), 6.f);
+  if (ACT == ACT_RELU6) return __builtin_amdgcn_fmed3f(z, 0.f, 6.f);   // one instruction; fminf(fmaxf()) adds a canonicalising max
   if (ACT == ACT_LRELU) return fmaxf(LRELU_ALPHA * z, z);
   if (ACT == ACT_TANH)  return tanhf(z);
   return z;
