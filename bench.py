@@ -152,6 +152,13 @@ def main():
     times = L.engine.kernel_times_ms()
     L.engine.kernel_events = None
     losses = L.losses()
+    # the acting path alone (no learning): vector steps of all environments, one launch each
+    barrier()
+    ta = time.perf_counter()
+    for _ in range(200):
+        L.rollout_step()
+    barrier()
+    acting = world * n_env * 200 / (time.perf_counter() - ta)
 
     if rank == 0:
         # median over the eager pass: robust against the first launches (lazy work-array setup)
@@ -166,6 +173,7 @@ def main():
             "config": {"workload": "curious_gan_ddpg_arm_b4096", "envs_per_gpu": n_env, "batch_per_gpu": batch,
                        "replay_rows_per_gpu": CAPACITY, "global_batch": batch * world, "parallelism": f"dp{world}", "launch": launch},
             "env_steps_per_s": round(world * n_env * args.steps / dt, 1),
+            "acting_only_env_steps_per_s": round(acting, 1),
             "kernel_ms": {k: round(v, 4) for k, v in sorted(avg_ms.items())},
             "losses": {k: round(v, 6) for k, v in losses.items()},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 3), "peak": PEAK_FP32_TFLOPS,
