@@ -290,6 +290,19 @@ int rlgan_philox_normal(float* out, int n_pairs, uint64_t seed, uint32_t stream_
 int rlgan_philox_uniform(double* out, int n_pairs, uint64_t seed, uint32_t stream_id, uint64_t index0,
                          const int64_t* step, int64_t step_mul, void* stream);
 
+/* ---- uint8 frame replay of the pixel variants ------------------------------------------------------
+ * The reference keeps Python lists of float32 frame stacks (Conv_model.py:102-157) that its environment
+ * wrapper produced as uint8 * (1/255) (env_wrapper.py:44,58).  The ring holds the uint8 stacks
+ * ([slots][frame_bytes], frame_bytes a multiple of 4); the gather applies the scale, the same float32
+ * product bit for bit.
+ *   store : ring[slot_idx[i], :] = frames[i, :]       (slot rule of the reference: host side)
+ *   gather: out[i, :] = float(ring[idx[i], :]) * scale, out float32 [n][frame_bytes], 16-byte aligned;
+ *           an index outside [0, slots) gives a zero frame. */
+int rlgan_frames_store(uint8_t* ring, int64_t slots, int32_t frame_bytes, const uint8_t* frames, int32_t n,
+                       const int64_t* slot_idx, void* stream);
+int rlgan_frames_gather(const uint8_t* ring, int64_t slots, int32_t frame_bytes, const int64_t* idx, int32_t n, float scale,
+                        float* out, void* stream);
+
 /* ---- fused acting path for n_env environments (Curious_GAN.py:190-198,222-234) -------------------
  * a = clip(actor(s) + var*z, -1, 1); g = G(s, a); (s', r, done) = env.step(a);
  * curious_r = r + ita*(1 - D(s, a, g)); row = [s, s', g, a, r, curious_r] -> replay ring at

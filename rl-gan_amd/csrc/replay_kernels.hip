@@ -3,6 +3,8 @@
 #include "rlgan_device.h"
 #include "rlgan_host.h"
 #include "rlgan_rng.h"
+#include <algorithm>
+#include <cstdint>
 
 using namespace rlgan;
 
@@ -73,6 +75,46 @@ __global__ void philox_uniform_kernel(double* out, int n_pairs, unsigned long lo
 
 inline int launched() { return (int)hipGetLastError(); }
 
+// ---------------------------------------------------------------- uint8 frame replay (pixel variants)
+// The reference keeps Python lists of float32 frame stacks (Conv_model.py:102-157) that the environment
+// wrapper produced as uint8 * (1/255) (env_wrapper.py:44,58); here the ring holds the uint8 stacks and the
+// gather applies the scale, bit for bit the same float32 product.  Both kernels move 4 pixels per thread
+// and step (one 32-bit load, one 128-bit store in the gather): pure HBM streaming.
+__global__ __launch_bounds__(256) void frames_store_kernel(uint32_t* __restrict__ ring, long long slots, int words,
+                                                           const uint32_t* __restrict__ frames, const int64_t* __restrict__ slot_idx) {
+  const long long slot = slot_idx[blockIdx.y];
+  if (slot < 0 || slot >= slots) return;
+  const uint32_t* src = frames + (size_t)blockIdx.y * words;
+  uint32_t* dst = ring + (size_t)slot * words;
+  for (int w0 = blockIdx.x * 1024 + threadIdx.x; w0 < words; w0 += gridDim.x * 1024) {
+    uint32_t v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = w0 + j * 256 < words ? src[w0 + j * 256] : 0u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (w0 + j * 256 < words) dst[w0 + j * 256] = v[j];
+  }
+}
+
+__global__ __launch_bounds__(256) void frames_gather_kernel(const uint32_t* __restrict__ ring, long long slots, int words,
+                                                            const int64_t* __restrict__ idx, float scale, f32x4* __restrict__ out) {
+  const long long slot = idx[blockIdx.y];
+  const bool ok = slot >= 0 && slot < slots;
+  const uint32_t* src = ring + (size_t)(ok ? slot : 0) * words;
+  f32x4* dst = out + (size_t)blockIdx.y * words;
+  // four independent loads in flight per thread before the first store
+  for (int w0 = blockIdx.x * 1024 + threadIdx.x; w0 < words; w0 += gridDim.x * 1024) {
+    uint32_t v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = (ok && w0 + j * 256 < words) ? src[w0 + j * 256] : 0u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (w0 + j * 256 < words)
+        dst[w0 + j * 256] = f32x4{(float)(v[j] & 255u) * scale, (float)((v[j] >> 8) & 255u) * scale,
+                                  (float)((v[j] >> 16) & 255u) * scale, (float)(v[j] >> 24) * scale};
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -125,6 +167,26 @@ int rlgan_philox_uniform(double* out, int n_pairs, uint64_t seed, uint32_t strea
   hipLaunchKernelGGL(philox_uniform_kernel, dim3(cdiv(n_pairs, 256)), dim3(256), 0, (hipStream_t)stream,
                      out, n_pairs, (unsigned long long)seed, stream_id, (unsigned long long)index0,
                      (const long long*)step, (long long)step_mul);
+  return launched();
+}
+
+int rlgan_frames_store(uint8_t* ring, int64_t slots, int32_t frame_bytes, const uint8_t* frames, int32_t n,
+                       const int64_t* slot_idx, void* stream) {
+  if (!ring || !frames || !slot_idx || slots <= 0 || frame_bytes <= 0 || n <= 0 || n > 65535) return RLGAN_E_ARG;
+  if ((frame_bytes & 3) || ((uintptr_t)ring & 3) || ((uintptr_t)frames & 3)) return RLGAN_E_ALIGN;
+  const int words = frame_bytes / 4;
+  hipLaunchKernelGGL(frames_store_kernel, dim3(std::min(cdiv(words, 1024), 64), n), dim3(256), 0, (hipStream_t)stream,
+                     (uint32_t*)ring, (long long)slots, words, (const uint32_t*)frames, slot_idx);
+  return launched();
+}
+
+int rlgan_frames_gather(const uint8_t* ring, int64_t slots, int32_t frame_bytes, const int64_t* idx, int32_t n, float scale,
+                        float* out, void* stream) {
+  if (!ring || !idx || !out || slots <= 0 || frame_bytes <= 0 || n <= 0 || n > 65535) return RLGAN_E_ARG;
+  if ((frame_bytes & 3) || ((uintptr_t)ring & 3) || ((uintptr_t)out & 15)) return RLGAN_E_ALIGN;
+  const int words = frame_bytes / 4;
+  hipLaunchKernelGGL(frames_gather_kernel, dim3(std::min(cdiv(words, 1024), 64), n), dim3(256), 0, (hipStream_t)stream,
+                     (const uint32_t*)ring, (long long)slots, words, idx, scale, (f32x4*)out);
   return launched();
 }
 

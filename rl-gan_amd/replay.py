@@ -109,3 +109,77 @@ class DeviceMemory:
     def sample(self, n: int) -> np.ndarray:
         """[n, dims] float64 host array, like the reference's `data[indices, :]`."""
         return self.sample_device(n).cpu().numpy().astype(np.float64)
+
+
+class FrameMemory:
+    """Replay of frame stacks for the pixel variants: the reference's `Conv_model.Memory` (Conv_model.py:102-157)
+    for its image fields, with the frames kept as the uint8 stacks the environment wrapper scales by 1/255
+    (env_wrapper.py:44,58) instead of float32 lists -- a quarter of the memory, and the gather restores the
+    same float32 values bit for bit.  Slot rule of the reference: transitions are appended while
+    `pointer <= capacity` (capacity + 1 slots exist) and then overwrite slot `pointer % capacity`;
+    `sample` draws from `len` = min(pointer, capacity + 1) slots (Conv_model.py:119-147).
+
+    rng: as for DeviceMemory (None: NumPy's global legacy stream, like the reference)."""
+
+    SCALE = 1.0 / 255
+
+    def __init__(self, capacity: int, shape, rng: Optional[MT19937Device] = None):
+        self.capacity, self.shape = int(capacity), tuple(int(v) for v in shape)
+        self.frame_bytes = int(np.prod(self.shape))
+        assert self.frame_bytes % 4 == 0, "frame stacks are moved four pixels at a time"
+        dev = device()
+        self.slots = self.capacity + 1
+        self._s = torch.zeros((self.slots, self.frame_bytes), dtype=torch.uint8, device=dev)
+        self._s_next = torch.zeros((self.slots, self.frame_bytes), dtype=torch.uint8, device=dev)
+        self.pointer = 0
+        self.len = 0
+        self.rng = rng
+        self._global_rng = MT19937Device() if rng is None else None
+
+    def _slots_for(self, n: int) -> torch.Tensor:
+        p = np.arange(self.pointer, self.pointer + n, dtype=np.int64)
+        return torch.from_numpy(np.where(p > self.capacity, p % self.capacity, p)).to(self._s.device)
+
+    def store_transitions(self, s_u8, s_next_u8) -> None:
+        """s_u8, s_next_u8: uint8 [n, *shape] (torch on the device, or NumPy): n consecutive transitions."""
+        fr = []
+        for f in (s_u8, s_next_u8):
+            t = torch.from_numpy(np.ascontiguousarray(f)) if isinstance(f, np.ndarray) else f
+            assert t.dtype == torch.uint8
+            fr.append(t.to(self._s.device).reshape(-1, self.frame_bytes).contiguous())
+        n = fr[0].shape[0]
+        assert fr[1].shape[0] == n and n <= self.capacity, "one call must not write a slot twice"
+        slots = self._slots_for(n)
+        for ring, t in ((self._s, fr[0]), (self._s_next, fr[1])):
+            check(lib.rlgan_frames_store(ring.data_ptr(), self.slots, self.frame_bytes, t.data_ptr(), n, slots.data_ptr(), _stream()),
+                  "rlgan_frames_store")
+        self.pointer += n
+        self.len = min(self.pointer, self.slots)
+
+    def store_transition(self, s_u8, s_next_u8) -> None:
+        self.store_transitions(np.asarray(s_u8)[None], np.asarray(s_next_u8)[None])
+
+    def sample_indices(self, n: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        assert self.len > 0
+        if self.rng is not None:
+            return self.rng.choice(self.len, n, out)
+        st = np.random.get_state()
+        self._global_rng.set_numpy_state(st)
+        idx = self._global_rng.choice(self.len, n, out)
+        np.random.set_state(self._global_rng.get_numpy_state(st[3], st[4]))
+        return idx
+
+    def gather(self, idx: torch.Tensor, which: str = "s", out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """float32 [n, *shape] = uint8 frames * (1/255) of the slots idx (int64, device)."""
+        ring = self._s if which == "s" else self._s_next
+        n = idx.numel()
+        if out is None:
+            out = torch.empty((n,) + self.shape, dtype=torch.float32, device=ring.device)
+        check(lib.rlgan_frames_gather(ring.data_ptr(), self.slots, self.frame_bytes, idx.data_ptr(), n, self.SCALE, out.data_ptr(),
+                                      _stream()), "rlgan_frames_gather")
+        return out
+
+    def sample(self, n: int):
+        """(indices, b_s, b_s_) on the device: Conv_model.py:145-157 for the two image fields."""
+        idx = self.sample_indices(n)
+        return idx, self.gather(idx, "s"), self.gather(idx, "s_")

@@ -1,0 +1,122 @@
+"""uint8 frame replay on the device (rlgan_frames_store / rlgan_frames_gather, FrameMemory) against the
+reference-produced fixture and the oracle: slots, indices and the scaled float32 frames bit for bit.
+Reference: Conv_model.py:102-157, env_wrapper.py:44,58."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from oracle import frames as OF
+
+pytestmark = pytest.mark.gpu
+
+
+def test_fixture_replay_bit_exact():
+    import rl_gan_amd as R
+    d = np.load(os.path.join(GOLDEN, "pixel_memory.npz"))
+    cap, shape = int(d["capacity"]), d["frames_s"].shape[1:]
+    m = R.FrameMemory(cap, shape)
+    for i, (s, s_) in enumerate(zip(d["frames_s"], d["frames_s_"])):
+        m.store_transition(s, s_)
+        assert m.pointer == d["pointers"][i] and m.len == d["lens"][i]
+    all_slots = torch.arange(cap + 1, device="cuda")
+    np.testing.assert_array_equal(m.gather(all_slots, "s").cpu().numpy(), d["data_s"])
+    np.testing.assert_array_equal(m.gather(all_slots, "s_").cpu().numpy(), d["data_s_"])
+    np.random.seed(int(d["sample_seed"]))
+    idx, b_s, b_s_ = m.sample(len(d["indices"]))
+    np.testing.assert_array_equal(idx.cpu().numpy(), d["indices"])
+    np.testing.assert_array_equal(b_s.cpu().numpy(), d["b_s"])
+    np.testing.assert_array_equal(b_s_.cpu().numpy(), d["b_s_"])
+    # the global stream moved on exactly as in the reference
+    np.random.seed(int(d["sample_seed"])); np.random.choice(cap + 1, size=len(d["indices"]))
+    ref_next = np.random.randint(1 << 30)
+    np.random.seed(int(d["sample_seed"])); m.sample(len(d["indices"]))
+    assert np.random.randint(1 << 30) == ref_next
+
+
+@pytest.mark.parametrize("chunk", [1, 5, 16])
+def test_batched_stores_match_oracle(chunk):
+    import rl_gan_amd as R
+    rs = np.random.RandomState(4)
+    cap, shape, n = 16, (12, 10, 4), 61
+    fs = rs.randint(0, 256, (n,) + shape).astype(np.uint8)
+    fs_ = rs.randint(0, 256, (n,) + shape).astype(np.uint8)
+    o = OF.FrameMemory(cap)
+    m = R.FrameMemory(cap, shape, rng=R.MT19937Device(9))
+    for i in range(0, n, chunk):
+        for j in range(i, min(i + chunk, n)):
+            o.store_transition(fs[j], fs_[j])
+        m.store_transitions(torch.from_numpy(fs[i:i + chunk]).cuda(), fs_[i:i + chunk])
+        assert (m.pointer, m.len) == (o.pointer, o.len)
+        sl = torch.arange(m.len, device="cuda")
+        np.testing.assert_array_equal(m.gather(sl, "s").cpu().numpy(), np.array(o.data_s))
+        np.testing.assert_array_equal(m.gather(sl, "s_").cpu().numpy(), np.array(o.data_s_))
+    idx, b_s, b_s_ = m.sample(37)
+    oi, ob, ob_ = o.sample(37, np.random.RandomState(9))
+    np.testing.assert_array_equal(idx.cpu().numpy(), oi)
+    np.testing.assert_array_equal(b_s.cpu().numpy(), ob)
+    np.testing.assert_array_equal(b_s_.cpu().numpy(), ob_)
+
+
+def test_all_byte_values_scale_like_numpy():
+    import rl_gan_amd as R
+    m = R.FrameMemory(3, (16, 16, 1))
+    f = np.arange(256, dtype=np.uint8).reshape(1, 16, 16, 1)
+    m.store_transitions(f, f[:, ::-1].copy())
+    z = torch.zeros(1, dtype=torch.int64, device="cuda")
+    np.testing.assert_array_equal(m.gather(z, "s").cpu().numpy(), OF.scaled(f))
+    np.testing.assert_array_equal(m.gather(z, "s_").cpu().numpy(), OF.scaled(f[:, ::-1]))
+
+
+def test_full_size_minibatch_properties():
+    """84x84x4 stacks (doom/mario shape of the reference), minibatch 4096: every gathered frame equals the
+    host's uint8 * (1/255) of the slot its index names, and out-of-range indices give zero frames."""
+    import rl_gan_amd as R
+    cap, shape, B = 2000, (84, 84, 4), 4096
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    m = R.FrameMemory(cap, shape, rng=R.MT19937Device(2))
+    for i in range(0, cap + 1, 667):
+        k = min(667, cap + 1 - i)
+        f = torch.randint(0, 256, (k,) + shape, dtype=torch.uint8, device="cuda", generator=g)
+        m.store_transitions(f, 255 - f)
+    assert m.len == cap + 1
+    idx, b_s, b_s_ = m.sample(B)
+    np.testing.assert_array_equal(idx.cpu().numpy(), np.random.RandomState(2).choice(cap + 1, size=B))
+    scale = torch.tensor(np.float32(OF.SCALE), device="cuda")
+    want = m._s[idx].to(torch.float32) * scale
+    assert torch.equal(b_s.reshape(B, -1), want)
+    assert torch.equal(b_s_.reshape(B, -1), (255 - m._s[idx]).to(torch.float32) * scale)
+    bad = torch.tensor([-1, cap + 1, 3], dtype=torch.int64, device="cuda")
+    out = m.gather(bad)
+    assert float(out[:2].abs().max()) == 0.0 and torch.equal(out[2].reshape(-1), m._s[3].to(torch.float32) * scale)
+    # a store whose slot index is out of range writes nothing
+    before = m._s.clone()
+    from rl_gan_amd._lib import check, lib
+    check(lib.rlgan_frames_store(m._s.data_ptr(), m.slots, m.frame_bytes, before.data_ptr(), 2,
+                                     torch.tensor([-1, cap + 1], dtype=torch.int64, device="cuda").data_ptr(), None), "store")
+    torch.cuda.synchronize()
+    assert torch.equal(m._s, before)
+
+
+def test_argument_errors():
+    import rl_gan_amd as R
+    from rl_gan_amd._lib import lib
+    ring = torch.zeros(4 * 64 + 16, dtype=torch.uint8, device="cuda")
+    out = torch.zeros(4 * 64 + 8, dtype=torch.float32, device="cuda")
+    idx = torch.zeros(4, dtype=torch.int64, device="cuda")
+    E_ARG, E_ALIGN = -1, -5
+    p, o, i = ring.data_ptr(), out.data_ptr(), idx.data_ptr()
+    assert lib.rlgan_frames_gather(None, 4, 64, i, 4, 1.0, o, None) == E_ARG
+    assert lib.rlgan_frames_gather(p, 0, 64, i, 4, 1.0, o, None) == E_ARG
+    assert lib.rlgan_frames_gather(p, 4, 64, i, 0, 1.0, o, None) == E_ARG
+    assert lib.rlgan_frames_gather(p, 4, 64, i, 65536, 1.0, o, None) == E_ARG
+    assert lib.rlgan_frames_gather(p, 4, 62, i, 4, 1.0, o, None) == E_ALIGN
+    assert lib.rlgan_frames_gather(p + 1, 4, 64, i, 4, 1.0, o, None) == E_ALIGN
+    assert lib.rlgan_frames_gather(p, 4, 64, i, 4, 1.0, o + 4, None) == E_ALIGN
+    assert lib.rlgan_frames_store(p, 4, 64, None, 1, i, None) == E_ARG
+    assert lib.rlgan_frames_store(p, 4, 63, p, 1, i, None) == E_ALIGN
+    assert lib.rlgan_frames_store(p, 4, 64, p + 2, 1, i, None) == E_ALIGN
+    torch.cuda.synchronize()
