@@ -375,6 +375,17 @@ int rlgan_conv_build_dx_map(const rlgan_conv_t* conv, int32_t* map_dx);
 /* y[n, h_out, w_out, c_out] = act(conv(x[n, h, w, c_in]) + b); act_elu != 0: ELU, else linear. */
 int rlgan_conv_forward(const rlgan_conv_t* conv, const float* x, const float* wfrag, float* y, int n_images,
                        int act_elu, void* stream);
+/* First layer straight from the uint8 frame ring ([slots][h*w*c_in], see rlgan_frames_*): image i of the
+ * batch is ring slot idx[i] (idx NULL: slot i, n_images <= slots), an input value is float(byte) * scale, so
+ * the float32 frames of the reference's pixel replay (Conv_model.py:145-157, env_wrapper.py:44,58) are never
+ * written to memory.  Results are bit-equal to rlgan_frames_gather followed by the float32 entry point.
+ * An index outside [0, slots) reads as a zero image.  The first layer needs no input gradient. */
+int rlgan_conv_forward_u8(const rlgan_conv_t* conv, const uint8_t* ring, int64_t slots, const int64_t* idx, float scale,
+                          const float* wfrag, float* y, int n_images, int act_elu, void* stream);
+int rlgan_conv_backward_weights_u8(const rlgan_conv_t* conv, const uint8_t* ring, int64_t slots, const int64_t* idx, float scale,
+                                   const float* dz, const float* y_elu, float* slabs, int n_slabs, float* grad, int n_images,
+                                   void* stream);
+
 /* dz = dy * ELU'(y) elementwise, ELU' taken from the layer OUTPUT y (y > 0 ? 1 : y + 1). */
 int rlgan_elu_backward(const float* dy, const float* y, float* dz, int64_t n, void* stream);
 /* dx[n, h, w, c_in] from dz[n, h_out, w_out, c_out].  With wdx (see rlgan_conv_build_dx_map): one

@@ -15,10 +15,10 @@ from .replay import DeviceMemory, FrameMemory, MT19937Device
 from .engine import StepEngine, GradExchange, ActorState, CriticState, AdamState
 from .core import DeviceNet, Workspace, mlp_forward
 from .learner import CuriousLearner, LearnerConfig
-from .conv import ConvEncoder, ConvLayer, DenseLayer, DOOM_HEAD, universe_head
+from .conv import ConvEncoder, ConvLayer, DenseLayer, FrameRef, DOOM_HEAD, universe_head
 from .train import Agent, Settings, train, train_DDPG
 
 __all__ = ["Session", "placeholder", "set_random_seed", "Actor", "Critic", "Generator", "Discriminator", "Memory",
-           "DDPGMemory", "ArmEnv", "VecArmEnv", "DeviceMemory", "FrameMemory", "MT19937Device", "StepEngine", "GradExchange",
+           "DDPGMemory", "ArmEnv", "VecArmEnv", "DeviceMemory", "FrameMemory", "FrameRef", "MT19937Device", "StepEngine", "GradExchange",
            "CuriousLearner", "LearnerConfig", "DeviceNet", "mlp_forward", "ConvEncoder", "ConvLayer", "DenseLayer", "DOOM_HEAD",
            "universe_head", "Agent", "Settings", "train", "train_DDPG"]

@@ -165,6 +165,8 @@ PROTOTYPES = {
     "rlgan_elu_backward": [_vp, _vp, _vp, _i64, _vp],
     "rlgan_conv_backward_input": [C.POINTER(Conv), _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "rlgan_conv_backward_weights": [C.POINTER(Conv), _vp, _vp, _vp, _vp, _i, _vp, _i, _vp],
+    "rlgan_conv_forward_u8": [C.POINTER(Conv), _vp, C.c_int64, _vp, _f, _vp, _vp, _i, _i, _vp],
+    "rlgan_conv_backward_weights_u8": [C.POINTER(Conv), _vp, C.c_int64, _vp, _f, _vp, _vp, _vp, _i, _vp, _i, _vp],
     "rlgan_frames_store": [_vp, C.c_int64, _i, _vp, _i, _vp, _vp],
     "rlgan_frames_gather": [_vp, C.c_int64, _i, _vp, _i, _f, _vp, _vp],
     "rlgan_dense_slabs": [_i, _i, _i],

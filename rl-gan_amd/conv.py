@@ -21,6 +21,16 @@ def universe_head(n_convs: int = 4):
     return tuple((32, 3, 2) for _ in range(n_convs))            # Conv_model.py:36-49
 
 
+class FrameRef:
+    """A minibatch of frames named by slot indices into a uint8 replay ring: `ring` uint8 [slots, h*w*c],
+    `idx` int64 [n] on the device (None: slots 0..n-1), value = byte * scale (env_wrapper.py:44,58)."""
+
+    def __init__(self, ring: torch.Tensor, idx: Optional[torch.Tensor], scale: float = 1.0 / 255, n: Optional[int] = None):
+        self.ring, self.idx, self.scale = ring, idx, float(scale)
+        self.n = int(idx.numel() if idx is not None else (ring.shape[0] if n is None else n))
+        assert idx is None or (idx.is_cuda and idx.dtype == torch.int64 and idx.is_contiguous())
+
+
 class ConvLayer:
     """One conv2d + ELU layer: canonical parameters (HWIO kernel, then bias) and their fragment image."""
 
@@ -76,6 +86,26 @@ class ConvLayer:
         check(lib.rlgan_conv_forward(self.conv, x.data_ptr(), self.wfrag.data_ptr(), y.data_ptr(), n, 1 if act else 0, _stream()),
               "rlgan_conv_forward")
         return y
+
+    def forward_frames(self, frames: "FrameRef", act: bool = True) -> torch.Tensor:
+        """This layer on uint8 frames read in place from a replay ring (no float32 copy of the frames)."""
+        ring, idx, scale = frames.ring, frames.idx, frames.scale
+        n = frames.n
+        assert ring.is_cuda and ring.dtype == torch.uint8 and ring.is_contiguous() and ring.shape[1] == self.conv.h * self.conv.w * self.c_in
+        y = torch.empty((n, self.h_out, self.w_out, self.c_out), dtype=torch.float32, device=ring.device)
+        check(lib.rlgan_conv_forward_u8(self.conv, ring.data_ptr(), ring.shape[0], None if idx is None else idx.data_ptr(), scale,
+                                        self.wfrag.data_ptr(), y.data_ptr(), n, 1 if act else 0, _stream()), "rlgan_conv_forward_u8")
+        return y
+
+    def backward_frames(self, frames: "FrameRef", y: torch.Tensor, dy: torch.Tensor, act: bool = True) -> None:
+        """Weight gradient of a first layer whose input is the uint8 ring (fills self.grad; frames get no gradient)."""
+        ring, idx = frames.ring, frames.idx
+        if self._slabs is None:
+            self._slabs = torch.empty(self.n_slabs * self.geom.slab_floats, dtype=torch.float32, device=ring.device)
+        check(lib.rlgan_conv_backward_weights_u8(self.conv, ring.data_ptr(), ring.shape[0], None if idx is None else idx.data_ptr(),
+                                                 frames.scale, dy.data_ptr(), y.data_ptr() if act else None, self._slabs.data_ptr(),
+                                                 self.n_slabs, self.grad.data_ptr(), frames.n, _stream()),
+              "rlgan_conv_backward_weights_u8")
 
     def backward(self, x: torch.Tensor, y: torch.Tensor, dy: torch.Tensor, need_dx: bool = True, act: bool = True):
         """Gradients of this layer: fills self.grad (kernel then bias), returns dx or None."""
@@ -185,10 +215,11 @@ class ConvEncoder:
         self._acts: List[torch.Tensor] = []
         self._flat = self._out = None
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def forward(self, x) -> torch.Tensor:
+        """x: float32 frames [n, h, w, c], or a FrameRef (uint8 frames read in place by the first layer)."""
         self._acts = [x]
-        for L in self.layers:
-            x = L.forward(x)
+        for i, L in enumerate(self.layers):
+            x = L.forward_frames(x) if i == 0 and isinstance(x, FrameRef) else L.forward(x)
             self._acts.append(x)
         flat = x.reshape(x.shape[0], -1)
         if self.head is None:
@@ -202,5 +233,8 @@ class ConvEncoder:
             dfeat = self.head.backward(self._flat, self._out, dfeat.contiguous())
         dy = dfeat.reshape(self._acts[-1].shape).contiguous()
         for i in range(len(self.layers) - 1, -1, -1):
+            if i == 0 and isinstance(self._acts[0], FrameRef):
+                self.layers[0].backward_frames(self._acts[0], self._acts[1], dy)
+                return None
             dy = self.layers[i].backward(self._acts[i], self._acts[i + 1], dy, need_dx=need_dx or i > 0)
         return dy

@@ -16,9 +16,21 @@ using namespace rlgan;
 
 namespace {
 
+// n / d for 0 <= n < 2^31 as a multiply-high, an add and a shift (the per-pixel index arithmetic of these kernels
+// would otherwise cost more vector-ALU time than their matrix products): m = floor(2^32 (2^l - d) / d) + 1,
+// l = ceil(log2 d), q = (mulhi(m, n) + n) >> l.
+struct FastDiv { uint32_t m; int l; };
+inline FastDiv make_div(int d) {
+  int l = 0;
+  while ((1u << l) < (uint32_t)d) ++l;
+  return FastDiv{(uint32_t)((((uint64_t)1 << 32) * (((uint64_t)1 << l) - (uint64_t)d)) / (uint64_t)d + 1), l};
+}
+__device__ __forceinline__ int fdiv(int n, FastDiv f) { return (int)((__umulhi(f.m, (uint32_t)n) + (uint32_t)n) >> f.l); }
+
 struct ConvG {
   int H, W, Cin, Cout, k, s;      // input height/width/channels, output channels, kernel size, stride
   int Ho, Wo, K, NG, NT, rowlen;  // output size, patch length, k-groups (of 16, incl. bias row), column tiles, k*Cin
+  FastDiv dHoWo, dWo;             // divisors Ho*Wo and Wo
 };
 
 inline bool make_conv(const rlgan_conv_t* c, ConvG& g) {
@@ -27,70 +39,161 @@ inline bool make_conv(const rlgan_conv_t* c, ConvG& g) {
   g.H = c->h; g.W = c->w; g.Cin = c->c_in; g.Cout = c->c_out; g.k = c->k; g.s = c->stride;
   g.Ho = (c->h - c->k) / c->stride + 1; g.Wo = (c->w - c->k) / c->stride + 1;
   g.K = c->k * c->k * c->c_in; g.NG = cdiv(g.K + 1, 16); g.NT = cdiv(c->c_out, 16); g.rowlen = c->k * c->c_in;
+  if ((long long)c->h * c->w * c->c_in > 0x7fffffffll) return false;
+  g.dHoWo = make_div(g.Ho * g.Wo); g.dWo = make_div(g.Wo);
   return true;
 }
 
 __device__ __forceinline__ float elu_f(float z) { return z > 0.f ? z : expm1f(z); }
 __device__ __forceinline__ float elu_d(float y) { return y > 0.f ? 1.f : y + 1.f; }   // ELU' from the layer output
 
-// this lane's four consecutive patch elements k0..k0+3 of output pixel `pix` (k0 % 4 == 0; rowlen % 4 == 0,
-// so the four never straddle a kernel row); element K is the constant 1 of the bias row, zeros after it
-__device__ __forceinline__ f32x4 patch4(const ConvG& g, const float* __restrict__ x, int b, int oy, int ox, int k0) {
-  if (k0 >= g.K) return f32x4{k0 == g.K ? 1.f : 0.f, 0.f, 0.f, 0.f};
-  const int ky = k0 / g.rowlen, rem = k0 - ky * g.rowlen;
-  const float* p = x + (((size_t)b * g.H + (oy * g.s + ky)) * g.W + ox * g.s) * g.Cin + rem;
-  return *(const f32x4*)p;
+// Where a layer's input comes from.  `image(b)` = offset of image b in elements (negative: no such image, its
+// pixels read as zero); `load(base, e)` fetches elements e..e+3 of that image and `value(raw, base)` turns what
+// was fetched into float32.  The two are separate so that a kernel can keep several fetches in flight and only
+// touch their results when it multiplies them; for the same reason `load` has no branch around its memory
+// access (a wave would wait for every load where the branches join).
+struct SrcF32 {                       // float32 activations [n][H][W][Cin]
+  using Raw = f32x4;
+  const float* x;
+  size_t img;
+  __device__ __forceinline__ long long image(int b) const { return (long long)((size_t)b * img); }
+  __device__ __forceinline__ Raw load(long long base, size_t e) const { return *(const f32x4*)(x + base + e); }
+  __device__ __forceinline__ f32x4 value(Raw r, long long) const { return r; }
+};
+struct SrcU8 {                        // uint8 frame ring [slots][H*W*Cin]; image b = slot idx[b] (idx null: slot b); value = byte * scale
+  using Raw = uint32_t;
+  const uint8_t* ring;
+  const int64_t* idx;
+  long long slots;
+  size_t img;
+  float scale;
+  __device__ __forceinline__ long long image(int b) const {
+    const long long slot = idx ? idx[b] : b;
+    return slot >= 0 && slot < slots ? (long long)((size_t)slot * img) : -1;
+  }
+  __device__ __forceinline__ Raw load(long long base, size_t e) const { return *(const uint32_t*)(ring + (base < 0 ? 0 : base) + e); }
+  __device__ __forceinline__ f32x4 value(Raw v, long long base) const {
+    const float sc = base < 0 ? 0.f : scale;
+    return f32x4{(float)(v & 255u) * sc, (float)((v >> 8) & 255u) * sc, (float)((v >> 16) & 255u) * sc, (float)(v >> 24) * sc};
+  }
+};
+
+// Patch element table: entry q (patch elements 4q..4q+3; rowlen % 4 == 0, so the four never straddle a kernel
+// row) = their offset from the patch's first element in the image, -1 for the constant 1 of the bias row
+// (element K), -2 for the zeros after it.  Filled by all threads of a workgroup; a barrier must follow.
+__device__ __forceinline__ void fill_ktab(const ConvG& g, int* ktab) {
+  for (int q = threadIdx.x; q < g.NG * 4; q += blockDim.x) {
+    const int k0 = q * 4, ky = k0 / g.rowlen;
+    ktab[q] = k0 > g.K ? -2 : k0 == g.K ? -1 : ky * g.W * g.Cin + (k0 - ky * g.rowlen);
+  }
+}
+// the four patch elements of table entry `koff` for the patch whose first element is `pix` of the image at `base`:
+// fetch (always from inside the patch) and, later, the value
+template <class S>
+__device__ __forceinline__ typename S::Raw patch_load(const S& src, long long base, int pix, int koff) {
+  return src.load(base, (size_t)(pix + max(koff, 0)));
+}
+template <class S>
+__device__ __forceinline__ f32x4 patch_value(const S& src, typename S::Raw r, long long base, int koff) {
+  const f32x4 v = src.value(r, base);
+  return koff >= 0 ? v : f32x4{koff == -1 ? 1.f : 0.f, 0.f, 0.f, 0.f};
+}
+// image offset and first patch element of output pixel `prow` (< n_images * Ho * Wo)
+struct Pos { long long base; int pix; };
+template <class S>
+__device__ __forceinline__ Pos locate(const ConvG& g, const S& src, int prow) {
+  const int b = fdiv(prow, g.dHoWo), r = prow - b * (g.Ho * g.Wo), oy = fdiv(r, g.dWo), ox = r - oy * g.Wo;
+  return Pos{src.image(b), (oy * g.W + ox) * (g.s * g.Cin)};
 }
 
 // ---------------------------------------------------------------- forward
-// One wave = 16 output pixels x all column tiles; A operands straight from global memory in MFMA
-// layout (lane = (pixel l&15, k-quad l>>4)), B operands = weight fragments; double-buffered.
-template <int NT>
-__global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvG g, const float* __restrict__ x, const float* __restrict__ wfrag,
+// A workgroup keeps the layer's weight fragments in LDS and walks a contiguous range of 16-pixel tiles, its four
+// waves taking every fourth tile.  The weight fragment is the row operand and the patch (straight from global
+// memory in MFMA layout: lane = (pixel l&15, k-quad l>>4)) the column operand, so a lane ends up with four
+// consecutive channels of one pixel and writes them as one 16-byte store.  Patches are fetched PF k-groups at
+// a time, the next PF (of this tile or of the wave's next one) while the current ones are multiplied.
+template <int NT, class S>
+__global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvG g, const S src, const float* __restrict__ wfrag,
                                                        float* __restrict__ y, int M, int act_elu) {
+  extern __shared__ __attribute__((aligned(16))) float wlds[];
+  constexpr int PF = 4;
+  const int nfrag = g.NG * NT * 256;
+  int* ktab = (int*)(wlds + nfrag);
+  for (int e = threadIdx.x * 4; e < nfrag; e += 1024) *(f32x4*)(wlds + e) = *(const f32x4*)(wfrag + e);
+  fill_ktab(g, ktab);
+  __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int pix0 = (blockIdx.x * 4 + wave) * 16;
-  if (pix0 >= M) return;
-  const int prow = min(pix0 + (lane & 15), M - 1);
-  const int b = prow / (g.Ho * g.Wo), r = prow - b * (g.Ho * g.Wo), oy = r / g.Wo, ox = r - oy * g.Wo;
-  const int kq = (lane >> 4) * 4;
-  const float* wl = wfrag + lane * 4;
+  const int ntiles = (M + 15) / 16, per_wg = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int t_end = min(ntiles, ((int)blockIdx.x + 1) * per_wg);
+  int tile = blockIdx.x * per_wg + wave;
+  if (tile >= t_end) return;                               // no barrier follows
+  const int nchunks = (g.NG + PF - 1) / PF;
+  const int* kt = ktab + (lane >> 4);
+  const float* wl = wlds + lane * 4;
+  auto at = [&](int t) { return locate(g, src, min(t * 16 + (lane & 15), M - 1)); };
+  using Raw = typename S::Raw;
+  auto fetch = [&](const Pos& ps, int g0, Raw (&aa)[PF], int (&kk)[PF]) {
+#pragma unroll
+    for (int j = 0; j < PF; ++j) {                          // groups past the end repeat the last one and are not multiplied
+      kk[j] = kt[4 * min(g0 + j, g.NG - 1)];
+      aa[j] = patch_load(src, ps.base, ps.pix, kk[j]);
+    }
+  };
+  Pos cur = at(tile);
+  Raw a[PF];
+  int ka[PF];
   f32x4 acc[NT];
+  fetch(cur, 0, a, ka);
+  int chunk = 0;
+  for (;;) {
+    int ntile = tile, nchunk = chunk + 1;
+    Pos nxt = cur;
+    if (nchunk == nchunks) {
+      nchunk = 0;
+      ntile = tile + 4;
+      if (ntile < t_end) nxt = at(ntile);
+    }
+    const bool more = ntile < t_end;
+    Raw an[PF];
+    int kn[PF];
+    if (more) fetch(nxt, nchunk * PF, an, kn);
+    if (chunk == 0) {
 #pragma unroll
-  for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  f32x4 a = patch4(g, x, b, oy, ox, kq);
-  f32x4 w[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) w[t] = *(const f32x4*)(wl + t * 256);
-  for (int gi = 0; gi < g.NG; ++gi) {
-    f32x4 an = a, wn[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) wn[t] = w[t];
-    if (gi + 1 < g.NG) {
-      an = patch4(g, x, b, oy, ox, 16 * (gi + 1) + kq);
-#pragma unroll
-      for (int t = 0; t < NT; ++t) wn[t] = *(const f32x4*)(wl + ((gi + 1) * NT + t) * 256);
+      for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
+    for (int j = 0; j < PF; ++j) {
+      const int gi = chunk * PF + j;
+      if (gi < g.NG) {
+        f32x4 w[NT];
 #pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], w[t][m], acc[t], 0, 0, 0);
+        for (int t = 0; t < NT; ++t) w[t] = *(const f32x4*)(wl + (gi * NT + t) * 256);
+        const f32x4 av = patch_value(src, a[j], cur.base, ka[j]);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+#pragma unroll
+          for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[t][m], av[m], acc[t], 0, 0, 0);
+        }
+      }
     }
-    a = an;
+    if (chunk == nchunks - 1) {
+      // result fragment: rows = channels 16t + 4*(lane>>4) + i, column = pixel lane&15
+      const int p = tile * 16 + (lane & 15);
+      if (p < M) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t) w[t] = wn[t];
-  }
-  // D fragment: rows (pixels) 4*(lane>>4)+i, column lane&15
-  const int col = lane & 15;
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    const int n = 16 * t + col;
-    if (n >= g.Cout) continue;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int p = pix0 + (lane >> 4) * 4 + i;
-      if (p < M) y[(size_t)p * g.Cout + n] = act_elu ? elu_f(acc[t][i]) : acc[t][i];
+        for (int t = 0; t < NT; ++t) {
+          const int n0 = 16 * t + (lane >> 4) * 4;
+          if (n0 >= g.Cout) continue;                       // Cout % 4 == 0: four channels are in range together
+          f32x4 v = acc[t];
+          if (act_elu) v = f32x4{elu_f(v[0]), elu_f(v[1]), elu_f(v[2]), elu_f(v[3])};
+          *(f32x4*)(y + (size_t)p * g.Cout + n0) = v;
+        }
+      }
     }
+    if (!more) break;
+#pragma unroll
+    for (int j = 0; j < PF; ++j) { a[j] = an[j]; ka[j] = kn[j]; }
+    cur = nxt; tile = ntile; chunk = nchunk;
   }
 }
 
@@ -159,83 +262,99 @@ __host__ __device__ inline DxClass dx_class(const ConvG& g, int cls) {
   c.NG = cdiv(c.Kc, 16);
   return c;
 }
-struct DxOff { int off[MAX_CLASSES]; };    // float offset of every class's fragment image
+struct DxOff {                             // per class: float offset of its fragment image, divisors na*nb and nb, k-groups
+  int off[MAX_CLASSES];
+  FastDiv dper[MAX_CLASSES], dnb[MAX_CLASSES];
+  int max_ng;
+};
 
-// this lane's four consecutive elements kk0..kk0+3 of the gathered row of input pixel (a, bb) of a class
-// (Cout % 4 == 0: the four share one tap)
-__device__ __forceinline__ f32x4 dz4(const ConvG& g, const DxClass& c, const float* __restrict__ dz, const float* __restrict__ yelu,
-                                    int b, int a, int bb, int kk0) {
-  const f32x4 zero{0.f, 0.f, 0.f, 0.f};
-  if (kk0 >= c.Kc) return zero;
-  const int tap = kk0 / g.Cout, co = kk0 - tap * g.Cout;
-  const int u = tap / c.nkx, v = tap - u * c.nkx;
-  const int oy = a - u, ox = bb - v;
-  if (oy < 0 || oy >= g.Ho || ox < 0 || ox >= g.Wo) return zero;
-  const size_t at = (((size_t)b * g.Ho + oy) * g.Wo + ox) * g.Cout + co;
-  f32x4 d = *(const f32x4*)(dz + at);
-  if (yelu) {                                                     // dz is dY: times ELU'(y) on the way in
-    const f32x4 yv = *(const f32x4*)(yelu + at);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) d[i] *= elu_d(yv[i]);
+// Gathered-row table of a class: entry q (row elements 4q..4q+3; Cout % 4 == 0, so the four share one tap (u, v))
+// = {offset of those dZ elements from the dZ row of output pixel (a, bb), u | v << 16}, or {0, -1} past the row's end.
+__device__ __forceinline__ void fill_taptab(const ConvG& g, const DxClass& c, int* tapd, int* tapuv) {
+  for (int q = threadIdx.x; q < c.NG * 4; q += blockDim.x) {
+    const int kk0 = q * 4, tap = kk0 / g.Cout, co = kk0 - tap * g.Cout, u = tap / c.nkx, v = tap - u * c.nkx;
+    const bool in = kk0 < c.Kc;
+    tapd[q] = in ? (-u * g.Wo - v) * g.Cout + co : 0;
+    tapuv[q] = in ? (u | (v << 16)) : -1;
   }
-  return d;
+}
+// the fetch of one table entry for input pixel (a, bb) whose dZ row would start at element `pz`, and later its
+// value.  No branch around the loads (a wave would wait for each where the branches join): element 0 is read
+// instead and discarded.
+struct DzRaw { f32x4 d, y; bool ok; };
+__device__ __forceinline__ DzRaw dz_load(const ConvG& g, const float* __restrict__ dz, const float* __restrict__ yelu,
+                                         long long pz, int a, int bb, int td, int tuv) {
+  const int oy = a - (tuv & 0xffff), ox = bb - (tuv >> 16);
+  DzRaw r;
+  r.ok = tuv >= 0 && (unsigned)oy < (unsigned)g.Ho && (unsigned)ox < (unsigned)g.Wo;
+  const size_t at = r.ok ? (size_t)(pz + td) : 0;
+  r.d = *(const f32x4*)(dz + at);
+  r.y = yelu ? *(const f32x4*)(yelu + at) : f32x4{1.f, 1.f, 1.f, 1.f};   // dz is dY: times ELU'(y) when it is used
+  return r;
+}
+__device__ __forceinline__ f32x4 dz_value(const DzRaw& r) {
+  return r.ok ? f32x4{r.d[0] * elu_d(r.y[0]), r.d[1] * elu_d(r.y[1]), r.d[2] * elu_d(r.y[2]), r.d[3] * elu_d(r.y[3])}
+              : f32x4{0.f, 0.f, 0.f, 0.f};
 }
 
-// One wave = 16 input pixels of one class x all Cin column tiles; blockIdx.y = class.
+// One wave = 16 input pixels of one class x all Cin column tiles; blockIdx.y = class.  The class's kernel
+// fragment is the row operand and the gathered dZ row the column operand: a lane ends up with four consecutive
+// input channels of one pixel, its own, and writes them as one 16-byte store.
 template <int NT>
 __global__ __launch_bounds__(256) void conv_dx_kernel(const ConvG g, const DxOff offs, const float* __restrict__ dz,
                                                       const float* __restrict__ yelu, const float* __restrict__ wdx,
                                                       float* __restrict__ dx, int n_images) {
+  extern __shared__ int taps[];                 // [2][max_ng * 4]
   const DxClass c = dx_class(g, blockIdx.y);
+  int *tapd = taps, *tapuv = taps + offs.max_ng * 4;
+  fill_taptab(g, c, tapd, tapuv);
+  __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int per = c.na * c.nb;
-  const long long Ml = (long long)n_images * per;
-  const long long pix0 = ((long long)blockIdx.x * 4 + wave) * 16;
+  const int Ml = n_images * per;                // the host checked that it fits
+  const int pix0 = (blockIdx.x * 4 + wave) * 16;
   if (pix0 >= Ml) return;
-  const long long prow = min(pix0 + (lane & 15), Ml - 1);
-  const int b = (int)(prow / per), r = (int)(prow - (long long)b * per), a = r / c.nb, bb = r - a * c.nb;
-  const int kq = (lane >> 4) * 4;
+  const int prow = min(pix0 + (lane & 15), Ml - 1);
+  const int b = fdiv(prow, offs.dper[blockIdx.y]), r = prow - b * per, a = fdiv(r, offs.dnb[blockIdx.y]), bb = r - a * c.nb;
+  const long long pz = (((long long)b * g.Ho + a) * g.Wo + bb) * g.Cout;
+  const int q0 = lane >> 4;
   const float* wl = wdx + offs.off[blockIdx.y] + lane * 4;
   f32x4 acc[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   if (c.NG > 0) {
-    f32x4 av = dz4(g, c, dz, yelu, b, a, bb, kq);
+    DzRaw av = dz_load(g, dz, yelu, pz, a, bb, tapd[q0], tapuv[q0]);
     f32x4 w[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) w[t] = *(const f32x4*)(wl + t * 256);
     for (int gi = 0; gi < c.NG; ++gi) {
-      f32x4 an = av, wn[NT];
+      DzRaw an = av;
+      f32x4 wn[NT];
 #pragma unroll
       for (int t = 0; t < NT; ++t) wn[t] = w[t];
       if (gi + 1 < c.NG) {
-        an = dz4(g, c, dz, yelu, b, a, bb, 16 * (gi + 1) + kq);
+        an = dz_load(g, dz, yelu, pz, a, bb, tapd[4 * (gi + 1) + q0], tapuv[4 * (gi + 1) + q0]);
 #pragma unroll
         for (int t = 0; t < NT; ++t) wn[t] = *(const f32x4*)(wl + ((gi + 1) * NT + t) * 256);
       }
+      const f32x4 ad = dz_value(av);
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], w[t][m], acc[t], 0, 0, 0);
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[t][m], ad[m], acc[t], 0, 0, 0);
       }
       av = an;
 #pragma unroll
       for (int t = 0; t < NT; ++t) w[t] = wn[t];
     }
   }
-  // D fragment: rows (pixels) 4*(lane>>4)+i, column lane&15
-  const int col = lane & 15;
+  // result fragment: rows = input channels 16t + 4*(lane>>4) + i, column = pixel lane&15
+  if (pix0 + (lane & 15) >= Ml) return;
+  float* o = dx + (((size_t)b * g.H + (g.s * a + c.py)) * g.W + (g.s * bb + c.px)) * g.Cin;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const long long p = pix0 + (lane >> 4) * 4 + i;
-    if (p >= Ml) continue;
-    const int pb = (int)(p / per), pr = (int)(p - (long long)pb * per), pa = pr / c.nb, pbb = pr - pa * c.nb;
-    float* o = dx + (((size_t)pb * g.H + (g.s * pa + c.py)) * g.W + (g.s * pbb + c.px)) * g.Cin;
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const int n = 16 * t + col;
-      if (n < g.Cin) o[n] = acc[t][i];
-    }
+  for (int t = 0; t < NT; ++t) {
+    const int n0 = 16 * t + (lane >> 4) * 4;
+    if (n0 < g.Cin) *(f32x4*)(o + n0) = acc[t];           // Cin % 4 == 0: four channels are in range together
   }
 }
 
@@ -246,13 +365,15 @@ __global__ __launch_bounds__(256) void conv_dx_kernel(const ConvG g, const DxOff
 // kernel adds the slabs in workgroup order, so the result is bitwise reproducible.
 constexpr int WG_PIX = 16;   // pixels staged per step: small, so that several workgroups share a compute unit and one's
                              // staging overlaps another's MFMAs (64 left one workgroup per unit: 2.4x slower)
-template <int NT>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const ConvG g, const float* __restrict__ x, const float* __restrict__ dz,
+template <int NT, class S>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const ConvG g, const S src, const float* __restrict__ dz,
                                                          const float* __restrict__ yelu, float* __restrict__ slabs, int M, int pix_per_wg) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int KP = g.NG * 16, ldp = KP + 4, ldz = NT * 16 + 4;
   float* P = lds;                       // [WG_PIX][ldp]
   float* Z = lds + WG_PIX * ldp;        // [WG_PIX][ldz]
+  int* ktab = (int*)(Z + WG_PIX * ldz); // [KP / 4]
+  fill_ktab(g, ktab);                   // the loop's first barrier comes before its first use
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nstrips = g.NG, my_strips = (nstrips - wave + 3) / 4;
   constexpr int MAXS = 5;               // K+1 <= 320 rows (the widest layer has 288 + 1)
@@ -265,16 +386,23 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ConvG g, const fl
   const int p_begin = blockIdx.x * pix_per_wg, p_end = min(M, p_begin + pix_per_wg);
   for (int p0 = p_begin; p0 < p_end; p0 += WG_PIX) {
     __syncthreads();
-    // stage patches (16 bytes per thread and step) and dZ rows; pixels beyond the range are zero rows
-    for (int e = threadIdx.x; e < WG_PIX * (KP / 4); e += 256) {
-      const int pl = e / (KP / 4), k0 = (e - pl * (KP / 4)) * 4;
-      const int p = p0 + pl;
-      f32x4 v{0.f, 0.f, 0.f, 0.f};
-      if (p < p_end) {
-        const int b = p / (g.Ho * g.Wo), r = p - b * (g.Ho * g.Wo), oy = r / g.Wo, ox = r - oy * g.Wo;
-        v = patch4(g, x, b, oy, ox, k0);
+    // stage patches (sixteen threads per pixel, 16 bytes each per turn) and dZ rows; pixels beyond the range are zero rows
+    {
+      const int pl = threadIdx.x >> 4, p = p0 + pl;
+      const bool in = p < p_end;
+      const Pos ps = locate(g, src, in ? p : p_begin);
+      typename S::Raw raw[MAXS];                            // KP / 4 <= 16 * MAXS table entries: all fetches first
+      int kf[MAXS];
+#pragma unroll
+      for (int i = 0; i < MAXS; ++i) {
+        kf[i] = ktab[min((int)(threadIdx.x & 15) + 16 * i, KP / 4 - 1)];
+        raw[i] = patch_load(src, ps.base, ps.pix, kf[i]);
       }
-      *(f32x4*)(P + pl * ldp + k0) = v;
+#pragma unroll
+      for (int i = 0; i < MAXS; ++i) {
+        const int q = (threadIdx.x & 15) + 16 * i;
+        if (q < KP / 4) *(f32x4*)(P + pl * ldp + 4 * q) = in ? patch_value(src, raw[i], ps.base, kf[i]) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
     }
     for (int e = threadIdx.x; e < WG_PIX * NT * 16; e += 256) {
       const int pl = e / (NT * 16), n = e - pl * (NT * 16);
@@ -358,15 +486,86 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __r
 inline int dx_layout(const ConvG& g, DxOff* offs) {
   if (g.s * g.s > MAX_CLASSES || g.Cin > 64) return 0;
   const int ntc = cdiv(g.Cin, 16);
-  int total = 0;
+  int total = 0, max_ng = 0;
   for (int cls = 0; cls < g.s * g.s; ++cls) {
-    if (offs) offs->off[cls] = total;
-    total += dx_class(g, cls).NG * ntc * 256;
+    const DxClass c = dx_class(g, cls);
+    if (offs) {
+      offs->off[cls] = total;
+      offs->dper[cls] = make_div(std::max(1, c.na * c.nb));
+      offs->dnb[cls] = make_div(std::max(1, c.nb));
+    }
+    max_ng = std::max(max_ng, c.NG);
+    total += c.NG * ntc * 256;
   }
+  if (offs) offs->max_ng = max_ng;
   return total;
 }
 
 inline int launched() { return (int)hipGetLastError(); }
+
+template <class S>
+int launch_fwd(const ConvG& g, const S& src, const float* wfrag, float* y, int n_images, int act_elu, void* stream) {
+  const long long Ml = (long long)n_images * g.Ho * g.Wo;
+  if (Ml > 0x7fffffffll || ((uintptr_t)y & 15)) return RLGAN_E_ALIGN;
+  const int M = (int)Ml;
+  // workgroups per compute unit: as many as the LDS copies of the weights allow (eight at most: one wave per SIMD each)
+  const size_t lds = (size_t)g.NG * g.NT * 1024 + (size_t)g.NG * 16;
+  const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds));
+  const dim3 grid(std::min(cdiv(cdiv(M, 16), 4), 256 * per_cu)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+#define RLGAN_FW(NTV)                                                                                              \
+  {                                                                                                                \
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)conv_fwd_kernel<NTV, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL((conv_fwd_kernel<NTV, S>), grid, block, lds, st, g, src, wfrag, y, M, act_elu);                    \
+  }
+  switch (g.NT) {
+    case 1: RLGAN_FW(1) break;
+    case 2: RLGAN_FW(2) break;
+    case 3: RLGAN_FW(3) break;
+    default: RLGAN_FW(4) break;
+  }
+#undef RLGAN_FW
+  return launched();
+}
+
+template <class S>
+int launch_wgrad(const ConvG& g, const S& src, const float* dz, const float* y_elu, float* slabs, int n_slabs, float* grad,
+                 int n_images, void* stream) {
+  if (g.NG > 20) return RLGAN_E_DIMS;                       // five 16-row strips per wave
+  const long long Ml = (long long)n_images * g.Ho * g.Wo;
+  if (Ml > 0x7fffffffll) return RLGAN_E_ALIGN;
+  const int M = (int)Ml;
+  const int per = cdiv(cdiv(M, n_slabs), WG_PIX) * WG_PIX;  // pixels per workgroup, a multiple of the staging step
+  const int used = cdiv(M, per);                            // slabs actually written (<= n_slabs)
+  const int KP = g.NG * 16, NP = g.NT * 16;
+  const size_t lds = (size_t)(WG_PIX * (KP + 4) + WG_PIX * (NP + 4) + KP / 4) * sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid(used), block(256);
+#define RLGAN_WG(NTV)                                                                                              \
+  {                                                                                                                \
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<NTV, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL((conv_wgrad_kernel<NTV, S>), grid, block, lds, st, g, src, dz, y_elu, slabs, M, per);               \
+  }
+  switch (g.NT) {
+    case 1: RLGAN_WG(1) break;
+    case 2: RLGAN_WG(2) break;
+    case 3: RLGAN_WG(3) break;
+    default: RLGAN_WG(4) break;
+  }
+#undef RLGAN_WG
+  if (const int rc = launched()) return rc;
+  hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(cdiv((g.K + 1) * g.Cout, 16)), dim3(256), 0, st, slabs, used, KP, NP, g.K, g.Cout, grad);
+  return launched();
+}
+
+// uint8 source of a first layer: argument checks shared by the two entry points
+inline int make_u8(const ConvG& g, const uint8_t* ring, int64_t slots, const int64_t* idx, int n_images, float scale, SrcU8& src) {
+  if (!ring || slots <= 0) return RLGAN_E_ARG;
+  if ((uintptr_t)ring & 3) return RLGAN_E_ALIGN;
+  if (!idx && n_images > slots) return RLGAN_E_ARG;          // without an index array image i is slot i
+  src = SrcU8{ring, idx, (long long)slots, (size_t)g.H * g.W * g.Cin, scale};
+  return 0;
+}
 
 }  // namespace
 
@@ -417,18 +616,17 @@ int rlgan_conv_forward(const rlgan_conv_t* conv, const float* x, const float* wf
   ConvG g;
   if (!make_conv(conv, g)) return RLGAN_E_DIMS;
   if (!x || !wfrag || !y || n_images <= 0) return RLGAN_E_ARG;
-  const long long Ml = (long long)n_images * g.Ho * g.Wo;
-  if (Ml > 0x7fffffffll) return RLGAN_E_ALIGN;
-  const int M = (int)Ml;
-  const dim3 grid(cdiv(M, 64)), block(256);
-  hipStream_t st = (hipStream_t)stream;
-  switch (g.NT) {
-    case 1: hipLaunchKernelGGL(conv_fwd_kernel<1>, grid, block, 0, st, g, x, wfrag, y, M, act_elu); break;
-    case 2: hipLaunchKernelGGL(conv_fwd_kernel<2>, grid, block, 0, st, g, x, wfrag, y, M, act_elu); break;
-    case 3: hipLaunchKernelGGL(conv_fwd_kernel<3>, grid, block, 0, st, g, x, wfrag, y, M, act_elu); break;
-    default: hipLaunchKernelGGL(conv_fwd_kernel<4>, grid, block, 0, st, g, x, wfrag, y, M, act_elu); break;
-  }
-  return launched();
+  return launch_fwd(g, SrcF32{x, (size_t)g.H * g.W * g.Cin}, wfrag, y, n_images, act_elu, stream);
+}
+
+int rlgan_conv_forward_u8(const rlgan_conv_t* conv, const uint8_t* ring, int64_t slots, const int64_t* idx, float scale,
+                          const float* wfrag, float* y, int n_images, int act_elu, void* stream) {
+  ConvG g;
+  if (!make_conv(conv, g)) return RLGAN_E_DIMS;
+  if (!wfrag || !y || n_images <= 0) return RLGAN_E_ARG;
+  SrcU8 src;
+  if (const int rc = make_u8(g, ring, slots, idx, n_images, scale, src)) return rc;
+  return launch_fwd(g, src, wfrag, y, n_images, act_elu, stream);
 }
 
 int rlgan_elu_backward(const float* dy, const float* y, float* dz, int64_t n, void* stream) {
@@ -446,15 +644,17 @@ int rlgan_conv_backward_input(const rlgan_conv_t* conv, const float* dz, const f
     DxOff offs;
     if (dx_layout(g, &offs) == 0) return RLGAN_E_DIMS;
     const long long per = (long long)cdiv(g.H, g.s) * cdiv(g.W, g.s);          // pixels per image of the largest class
+    if ((long long)n_images * per > 0x7fffffffll || ((uintptr_t)dx & 15)) return RLGAN_E_ALIGN;
     const long long groups = cdiv((long long)n_images * per, 64);
-    if (groups > 0x7fffffffll) return RLGAN_E_ALIGN;
     const dim3 grid((unsigned)groups, g.s * g.s), block(256);
+    const size_t lds = (size_t)std::max(1, offs.max_ng) * 4 * 2 * sizeof(int);
+    if (lds > 64 * 1024) return RLGAN_E_DIMS;
     hipStream_t st = (hipStream_t)stream;
     switch (cdiv(g.Cin, 16)) {
-      case 1: hipLaunchKernelGGL(conv_dx_kernel<1>, grid, block, 0, st, g, offs, dz, y_elu, wdx, dx, n_images); break;
-      case 2: hipLaunchKernelGGL(conv_dx_kernel<2>, grid, block, 0, st, g, offs, dz, y_elu, wdx, dx, n_images); break;
-      case 3: hipLaunchKernelGGL(conv_dx_kernel<3>, grid, block, 0, st, g, offs, dz, y_elu, wdx, dx, n_images); break;
-      default: hipLaunchKernelGGL(conv_dx_kernel<4>, grid, block, 0, st, g, offs, dz, y_elu, wdx, dx, n_images); break;
+      case 1: hipLaunchKernelGGL(conv_dx_kernel<1>, grid, block, lds, st, g, offs, dz, y_elu, wdx, dx, n_images); break;
+      case 2: hipLaunchKernelGGL(conv_dx_kernel<2>, grid, block, lds, st, g, offs, dz, y_elu, wdx, dx, n_images); break;
+      case 3: hipLaunchKernelGGL(conv_dx_kernel<3>, grid, block, lds, st, g, offs, dz, y_elu, wdx, dx, n_images); break;
+      default: hipLaunchKernelGGL(conv_dx_kernel<4>, grid, block, lds, st, g, offs, dz, y_elu, wdx, dx, n_images); break;
     }
     return launched();
   }
@@ -469,31 +669,18 @@ int rlgan_conv_backward_weights(const rlgan_conv_t* conv, const float* x, const 
   ConvG g;
   if (!make_conv(conv, g)) return RLGAN_E_DIMS;
   if (!x || !dz || !slabs || !grad || n_images <= 0 || n_slabs <= 0) return RLGAN_E_ARG;
-  if (g.NG > 20) return RLGAN_E_DIMS;                       // five 16-row strips per wave
-  const long long Ml = (long long)n_images * g.Ho * g.Wo;
-  if (Ml > 0x7fffffffll) return RLGAN_E_ALIGN;
-  const int M = (int)Ml;
-  const int per = cdiv(cdiv(M, n_slabs), WG_PIX) * WG_PIX;  // pixels per workgroup, a multiple of the staging step
-  const int used = cdiv(M, per);                            // slabs actually written (<= n_slabs)
-  const int KP = g.NG * 16, NP = g.NT * 16;
-  const size_t lds = (size_t)(WG_PIX * (KP + 4) + WG_PIX * (NP + 4)) * sizeof(float);
-  hipStream_t st = (hipStream_t)stream;
-  const dim3 grid(used), block(256);
-#define RLGAN_WG(NTV)                                                                                              \
-  {                                                                                                                \
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<NTV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-    hipLaunchKernelGGL(conv_wgrad_kernel<NTV>, grid, block, lds, st, g, x, dz, y_elu, slabs, M, per);                     \
-  }
-  switch (g.NT) {
-    case 1: RLGAN_WG(1) break;
-    case 2: RLGAN_WG(2) break;
-    case 3: RLGAN_WG(3) break;
-    default: RLGAN_WG(4) break;
-  }
-#undef RLGAN_WG
-  if (const int rc = launched()) return rc;
-  hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(cdiv((g.K + 1) * g.Cout, 16)), dim3(256), 0, st, slabs, used, KP, NP, g.K, g.Cout, grad);
-  return launched();
+  return launch_wgrad(g, SrcF32{x, (size_t)g.H * g.W * g.Cin}, dz, y_elu, slabs, n_slabs, grad, n_images, stream);
+}
+
+int rlgan_conv_backward_weights_u8(const rlgan_conv_t* conv, const uint8_t* ring, int64_t slots, const int64_t* idx, float scale,
+                                   const float* dz, const float* y_elu, float* slabs, int n_slabs, float* grad, int n_images,
+                                   void* stream) {
+  ConvG g;
+  if (!make_conv(conv, g)) return RLGAN_E_DIMS;
+  if (!dz || !slabs || !grad || n_images <= 0 || n_slabs <= 0) return RLGAN_E_ARG;
+  SrcU8 src;
+  if (const int rc = make_u8(g, ring, slots, idx, n_images, scale, src)) return rc;
+  return launch_wgrad(g, src, dz, y_elu, slabs, n_slabs, grad, n_images, stream);
 }
 
 }  // extern "C"

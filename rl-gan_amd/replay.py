@@ -179,6 +179,11 @@ class FrameMemory:
                                       _stream()), "rlgan_frames_gather")
         return out
 
+    def ref(self, idx: torch.Tensor, which: str = "s"):
+        """The frames of slots idx as a FrameRef: a conv encoder reads them in place, without the float32 copy."""
+        from .conv import FrameRef
+        return FrameRef(self._s if which == "s" else self._s_next, idx, self.SCALE)
+
     def sample(self, n: int):
         """(indices, b_s, b_s_) on the device: Conv_model.py:145-157 for the two image fields."""
         idx = self.sample_indices(n)

@@ -120,3 +120,52 @@ def test_argument_errors():
     assert lib.rlgan_frames_store(p, 4, 63, p, 1, i, None) == E_ALIGN
     assert lib.rlgan_frames_store(p, 4, 64, p + 2, 1, i, None) == E_ALIGN
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("spec", ["doom", "universe"])
+def test_encoder_reads_uint8_ring_in_place(spec):
+    """First conv layer on the uint8 ring through the index array == the same layer on the gathered float32
+    frames, bit for bit (forward, ELU output, weight gradient), Conv_model.py:15-24,36-56."""
+    import rl_gan_amd as R
+    cap, hw, n = 50, 42, 37
+    layers = R.DOOM_HEAD[:3] if spec == "doom" else R.universe_head(3)
+    enc = R.ConvEncoder(hw, hw, 4, layers, rng=np.random.RandomState(3), bias_init=0.001, dense=64)
+    mem = R.FrameMemory(cap, (hw, hw, 4), rng=R.MT19937Device(6))
+    g = torch.Generator(device="cuda"); g.manual_seed(1)
+    f = torch.randint(0, 256, (cap,) + (hw, hw, 4), dtype=torch.uint8, device="cuda", generator=g)
+    mem.store_transitions(f, f.flip(0))
+    idx = mem.sample_indices(n)
+    for which in ("s", "s_"):
+        x = mem.gather(idx, which)
+        feat_a = enc.forward(x).clone()
+        d = torch.randn(feat_a.shape, device="cuda", generator=g)
+        enc.backward(d)
+        grads_a = [L.grad.clone() for L in enc.layers] + [enc.head.grad.clone()]
+        feat_b = enc.forward(mem.ref(idx, which))
+        assert torch.equal(feat_a, feat_b)
+        assert enc.backward(d) is None
+        for ga, L in zip(grads_a, enc.layers + [enc.head]):
+            assert torch.equal(ga, L.grad)
+    # no index array: image i is slot i; an index out of range reads as a zero image
+    L0 = enc.layers[0]
+    y_all = L0.forward_frames(R.FrameRef(mem._s, None, mem.SCALE, n=5))
+    assert torch.equal(y_all, L0.forward(mem.gather(torch.arange(5, device="cuda"))))
+    bad = torch.tensor([cap + 1, 2, -3], dtype=torch.int64, device="cuda")
+    y_bad = L0.forward_frames(mem.ref(bad))
+    assert torch.equal(y_bad, L0.forward(mem.gather(bad)))
+
+
+def test_u8_conv_argument_errors():
+    import rl_gan_amd as R
+    from rl_gan_amd._lib import lib
+    L = R.ConvLayer(12, 12, 4, 8, 3, 2, rng=np.random.RandomState(0))
+    ring = torch.zeros((4, 12 * 12 * 4 + 4), dtype=torch.uint8, device="cuda")
+    y = torch.zeros(8 * L.h_out * L.w_out * 8, dtype=torch.float32, device="cuda")
+    E_ARG, E_ALIGN = -1, -5
+    r, w, yo = ring.data_ptr(), L.wfrag.data_ptr(), y.data_ptr()
+    assert lib.rlgan_conv_forward_u8(L.conv, None, 4, None, 1.0, w, yo, 2, 1, None) == E_ARG
+    assert lib.rlgan_conv_forward_u8(L.conv, r, 0, None, 1.0, w, yo, 2, 1, None) == E_ARG
+    assert lib.rlgan_conv_forward_u8(L.conv, r, 4, None, 1.0, w, yo, 5, 1, None) == E_ARG      # more images than slots
+    assert lib.rlgan_conv_forward_u8(L.conv, r + 2, 4, None, 1.0, w, yo, 2, 1, None) == E_ALIGN
+    assert lib.rlgan_conv_backward_weights_u8(L.conv, r, 4, None, 1.0, None, None, yo, 4, L.grad.data_ptr(), 2, None) == E_ARG
+    torch.cuda.synchronize()

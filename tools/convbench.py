@@ -25,6 +25,17 @@ for name, hw, spec in (("doom 84x84x4", 84, R.DOOM_HEAD), ("universe(2) 84x84x4"
         dy = torch.randn_like(acts[i + 1])
         t2 = timeit(lambda: L.backward(acts[i], acts[i + 1], dy, need_dx=i > 0))
         print(f"    layer {i}: {L.conv.h}x{L.conv.w}x{L.c_in} -> {L.h_out}x{L.w_out}x{L.c_out}  fwd {t1:8.1f} us {2 * m * B / t1 / 1e6:6.1f} TF/s   bwd {t2:8.1f} us")
+    # first layer reading uint8 frames in place from a replay ring through an index array
+    mem = R.FrameMemory(3 * B, (hw, hw, 4), rng=R.MT19937Device(1))
+    for j in range(3):
+        mem.store_transitions((x * 255).to(torch.uint8), (x * 255).to(torch.uint8))
+    ref = mem.ref(mem.sample_indices(B))
+    L, y1 = enc.layers[0], acts[1]
+    dy = torch.randn_like(y1)
+    t0 = timeit(lambda: mem.gather(ref.idx))
+    t1 = timeit(lambda: L.forward_frames(ref))
+    t2 = timeit(lambda: L.backward_frames(ref, y1, dy))
+    print(f"    layer 0 on uint8 ring: gather alone {t0:8.1f} us; fwd in place {t1:8.1f} us; weight gradient in place {t2:8.1f} us")
 
 for k in (64, 2592, 12800):
     L = R.DenseLayer(k, 256, rng=np.random.RandomState(0))
