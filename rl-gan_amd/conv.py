@@ -65,7 +65,10 @@ class ConvLayer:
             self.wdx = torch.zeros(g.wdx_floats, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(self.n_params, dtype=torch.float32, device=dev)
         self.gather_dx = False   # True: input gradient by the vector-ALU gather even where the MFMA form exists
-        self.n_slabs = 1024      # partial weight-gradient images (one per workgroup of the reduction over pixels)
+        # partial weight-gradient images: one per workgroup of the reduction over pixels; layers with few patch
+        # elements (at most 128 incl. the bias row, and 32 filters) take one per wave when the batch is large
+        self.n_slabs = 1024
+        self._small = k * k * c_in + 1 <= 128 and c_out <= 32
         self._slabs = None
         self.pack()
 
@@ -73,6 +76,16 @@ class ConvLayer:
         check(lib.rlgan_pack_weights(self.canon.data_ptr(), self.n_params, self.map_f.data_ptr(), self.wfrag.data_ptr(),
                                      None if self.wdx is None else self.map_dx.data_ptr(),
                                      None if self.wdx is None else self.wdx.data_ptr(), _stream()), "rlgan_pack_weights")
+
+    def _slab_buffer(self, n_images: int):
+        """(buffer, slab count) for the weight gradient over n_images."""
+        ns = self.n_slabs
+        if self._small and n_images * self.h_out * self.w_out >= 4096 * 256:
+            ns = max(ns, 4096)
+        need = ns * self.geom.slab_floats
+        if self._slabs is None or self._slabs.numel() < need:
+            self._slabs = torch.empty(need, dtype=torch.float32, device=self.canon.device)
+        return self._slabs, ns
 
     def kernel_bias(self) -> Tuple[np.ndarray, np.ndarray]:
         f = self.canon.cpu().numpy()
@@ -100,11 +113,10 @@ class ConvLayer:
     def backward_frames(self, frames: "FrameRef", y: torch.Tensor, dy: torch.Tensor, act: bool = True) -> None:
         """Weight gradient of a first layer whose input is the uint8 ring (fills self.grad; frames get no gradient)."""
         ring, idx = frames.ring, frames.idx
-        if self._slabs is None:
-            self._slabs = torch.empty(self.n_slabs * self.geom.slab_floats, dtype=torch.float32, device=ring.device)
+        slabs, ns = self._slab_buffer(frames.n)
         check(lib.rlgan_conv_backward_weights_u8(self.conv, ring.data_ptr(), ring.shape[0], None if idx is None else idx.data_ptr(),
-                                                 frames.scale, dy.data_ptr(), y.data_ptr() if act else None, self._slabs.data_ptr(),
-                                                 self.n_slabs, self.grad.data_ptr(), frames.n, _stream()),
+                                                 frames.scale, dy.data_ptr(), y.data_ptr() if act else None, slabs.data_ptr(),
+                                                 ns, self.grad.data_ptr(), frames.n, _stream()),
               "rlgan_conv_backward_weights_u8")
 
     def backward(self, x: torch.Tensor, y: torch.Tensor, dy: torch.Tensor, need_dx: bool = True, act: bool = True):
@@ -117,9 +129,8 @@ class ConvLayer:
         if act and not fuse:
             dz = torch.empty_like(dy)
             check(lib.rlgan_elu_backward(dy.data_ptr(), y.data_ptr(), dz.data_ptr(), dy.numel(), _stream()), "rlgan_elu_backward")
-        if self._slabs is None:
-            self._slabs = torch.empty(self.n_slabs * self.geom.slab_floats, dtype=torch.float32, device=x.device)
-        check(lib.rlgan_conv_backward_weights(self.conv, x.data_ptr(), dz.data_ptr(), yel, self._slabs.data_ptr(), self.n_slabs,
+        slabs, ns = self._slab_buffer(n)
+        check(lib.rlgan_conv_backward_weights(self.conv, x.data_ptr(), dz.data_ptr(), yel, slabs.data_ptr(), ns,
                                               self.grad.data_ptr(), n, _stream()), "rlgan_conv_backward_weights")
         if not need_dx:
             return None

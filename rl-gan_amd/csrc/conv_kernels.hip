@@ -456,6 +456,117 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ConvG g, const S 
   }
 }
 
+// Weight gradient of layers with few patch elements (at most 8 k-groups and 2 column tiles: the first layers).  There
+// the product per pixel is too small to pay for workgroup barriers, so every wave works alone: it walks its own
+// range of pixels 16 at a time, fetches patches and dZ rows in 16-byte pieces (lane = (pixel l&15, quad l>>4)),
+// turns them through a private piece of LDS into the operand layout (row operand = patch element, summed
+// dimension = pixel), multiplies all strips, and writes a slab of its own.  The next 16 pixels are fetched
+// while the current ones are multiplied.
+template <int NT, int MAXG, class S>
+__global__ __launch_bounds__(256) void conv_wgrad_small_kernel(const ConvG g, const S src, const float* __restrict__ dz,
+                                                               const float* __restrict__ yelu, float* __restrict__ slabs, int M,
+                                                               int pix_per_wave) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int NP = NT * 16, ldz = NP % 32 == 16 ? NP : NP + 16;     // row pitches = 16 mod 32: the four pixel rows a
+  const int KP = g.NG * 16, ldp = KP % 32 == 16 ? KP : KP + 16;       // transposed read touches fall on two bank halves
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int* ktab = (int*)lds;                                              // [KP / 4], shared by the waves
+  float* P = lds + KP / 4 + wave * 16 * (ldp + ldz);                  // this wave's [16][ldp]
+  float* Z = P + 16 * ldp;                                            // and [16][ldz]
+  fill_ktab(g, ktab);
+  __syncthreads();
+  const int wv = blockIdx.x * 4 + wave;
+  const int p_begin = wv * pix_per_wave, p_end = min(M, p_begin + pix_per_wave);
+  if (p_begin >= p_end) return;                                       // no barrier follows
+  const int px = lane & 15, q = lane >> 4;
+  f32x4 acc[MAXG][NT];
+#pragma unroll
+  for (int s = 0; s < MAXG; ++s) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[s][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  typename S::Raw ra[MAXG];
+  int kf[MAXG];
+  f32x4 rz[NT], ry[NT];
+  long long rbase;
+  auto fetch = [&](int p0) {
+    const int p = p0 + px;
+    const bool in = p < p_end;
+    const Pos ps = locate(g, src, in ? p : p_begin);
+    rbase = ps.base;
+#pragma unroll
+    for (int s = 0; s < MAXG; ++s) {
+      if (s < g.NG) {
+        const int k = ktab[4 * s + q];
+        kf[s] = in ? k : -2;                                          // pixels beyond the range: zero rows
+        ra[s] = patch_load(src, ps.base, ps.pix, k);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int col = 4 * (q + 4 * t);
+      const size_t at = in && col < g.Cout ? (size_t)p * g.Cout + col : 0;
+      rz[t] = *(const f32x4*)(dz + at);
+      ry[t] = yelu ? *(const f32x4*)(yelu + at) : f32x4{1.f, 1.f, 1.f, 1.f};   // dz is dY: times ELU'(y) on the way in
+    }
+  };
+  fetch(p_begin);
+  for (int p0 = p_begin; p0 < p_end; p0 += 16) {
+    const bool in = p0 + px < p_end;
+#pragma unroll
+    for (int s = 0; s < MAXG; ++s)
+      if (s < g.NG) *(f32x4*)(P + px * ldp + 16 * s + 4 * q) = patch_value(src, ra[s], rbase, kf[s]);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int col = 4 * (q + 4 * t);
+      const bool ok = in && col < g.Cout;
+      *(f32x4*)(Z + px * ldz + col) = ok ? f32x4{rz[t][0] * elu_d(ry[t][0]), rz[t][1] * elu_d(ry[t][1]), rz[t][2] * elu_d(ry[t][2]),
+                                                 rz[t][3] * elu_d(ry[t][3])}
+                                         : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (p0 + 16 < p_end) fetch(p0 + 16);
+    // the wave's own LDS accesses are carried out in order; the fence keeps the compiler from moving them
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // A[row = patch element][kk = pixel 4m + q], B[kk = pixel 4m + q][col = channel]
+    f32x4 bz[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m) bz[t][m] = Z[(4 * m + q) * ldz + 16 * t + px];
+    }
+#pragma unroll
+    for (int s = 0; s < MAXG; ++s) {
+      if (s < g.NG) {
+        f32x4 ap;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) ap[m] = P[(4 * m + q) * ldp + 16 * s + px];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+#pragma unroll
+          for (int t = 0; t < NT; ++t) acc[s][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[m], bz[t][m], acc[s][t], 0, 0, 0);
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  // slab [KP][NT*16]: result rows = patch elements 16s + 4q + i, column = channel 16t + px
+  float* out = slabs + (size_t)wv * KP * NP;
+#pragma unroll
+  for (int s = 0; s < MAXG; ++s) {
+    if (s < g.NG) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) out[(size_t)(16 * s + 4 * q + i) * NP + 16 * t + px] = acc[s][t][i];
+      }
+    }
+  }
+}
+
 // grad[(k, n)] in canonical order ([K][Cout] kernel, then bias[Cout]) = sum of the slabs.  A workgroup
 // handles 16 entries; 16 threads per entry each add a strided share of the slabs in index order and the
 // 16 partial sums are added in a fixed order, so the result does not depend on timing.
@@ -533,8 +644,24 @@ int launch_wgrad(const ConvG& g, const S& src, const float* dz, const float* y_e
                  int n_images, void* stream) {
   if (g.NG > 20) return RLGAN_E_DIMS;                       // five 16-row strips per wave
   const long long Ml = (long long)n_images * g.Ho * g.Wo;
-  if (Ml > 0x7fffffffll) return RLGAN_E_ALIGN;
+  if (Ml > 0x7fffffffll || ((uintptr_t)dz & 15) || (y_elu && ((uintptr_t)y_elu & 15))) return RLGAN_E_ALIGN;
   const int M = (int)Ml;
+  if (g.NG <= 8 && g.NT <= 2 && M / n_slabs >= 256) {        // few patch elements and long pixel ranges: one slab per wave, no workgroup barriers
+    const int KP = g.NG * 16, NP = g.NT * 16;
+    const int per = cdiv(cdiv(M, n_slabs), 16) * 16, used = cdiv(M, per);
+    const int ldp = KP % 32 == 16 ? KP : KP + 16, ldz = NP % 32 == 16 ? NP : NP + 16;
+    const size_t lds = (size_t)(KP / 4 + 4 * 16 * (ldp + ldz)) * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(cdiv(used, 4)), block(256);
+    if (g.NT == 1) {
+      hipLaunchKernelGGL((conv_wgrad_small_kernel<1, 8, S>), grid, block, lds, st, g, src, dz, y_elu, slabs, M, per);
+    } else {
+      hipLaunchKernelGGL((conv_wgrad_small_kernel<2, 8, S>), grid, block, lds, st, g, src, dz, y_elu, slabs, M, per);
+    }
+    if (const int rc = launched()) return rc;
+    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(cdiv((g.K + 1) * g.Cout, 16)), dim3(256), 0, st, slabs, used, KP, NP, g.K, g.Cout, grad);
+    return launched();
+  }
   const int per = cdiv(cdiv(M, n_slabs), WG_PIX) * WG_PIX;  // pixels per workgroup, a multiple of the staging step
   const int used = cdiv(M, per);                            // slabs actually written (<= n_slabs)
   const int KP = g.NG * 16, NP = g.NT * 16;

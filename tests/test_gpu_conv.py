@@ -128,3 +128,35 @@ def test_input_gradient_two_ways(h, cin, cout, k, st):
     L.gather_dx = True
     b = L.backward(x, y, dy)
     close(a.cpu().numpy(), b.cpu().numpy().astype(np.float64), what="dX mfma vs gather")
+
+
+@pytest.mark.parametrize("h,cin,cout,k,st,n", [(84, 4, 8, 5, 4, 7), (42, 4, 32, 3, 2, 9), (20, 8, 16, 3, 2, 40)])
+def test_weight_gradient_two_ways(h, cin, cout, k, st, n):
+    """Layers with few patch elements have two weight-gradient kernels (one slab per workgroup, or per wave when
+    every slab covers a long run of pixels): both against the float64 restatement, on float32 frames and on the
+    uint8 ring."""
+    import rl_gan_amd as R
+    from gpu_util import close
+    from oracle import conv as oc
+    rng = np.random.RandomState(h + cout)
+    L = R.ConvLayer(h, h, cin, cout, k, st, rng=rng, bias_init=0.01)
+    u8 = torch.randint(0, 256, (n, h * h * cin), dtype=torch.uint8, device="cuda")
+    x = (u8.to(torch.float32) * torch.tensor(np.float32(1.0 / 255), device="cuda")).reshape(n, h, h, cin)
+    y = L.forward(x)
+    dy = torch.randn_like(y)
+    w, b = L.kernel_bias()
+    w64 = w.astype(np.float64)
+    yo, cache = oc.conv_forward(x.cpu().numpy().astype(np.float64), w64, b.astype(np.float64), k, st)
+    _, dw, db = oc.conv_backward(dy.cpu().numpy().astype(np.float64), w64, cache, k, st)
+    want = np.concatenate([dw.ravel(), db.ravel()])
+    m = n * L.h_out * L.w_out
+    got = {}
+    for ns in (1024, max(4, m // 300)):          # pixels per slab: few (workgroup kernel) / at least 256 (wave kernel)
+        L.n_slabs, L._small = ns, False
+        L.grad.zero_()
+        L.backward(x, y, dy, need_dx=False)
+        got[ns] = L.grad.clone()
+        close(got[ns].cpu().numpy(), want, what=f"dW with {ns} slabs")
+        L.grad.zero_()
+        L.backward_frames(R.FrameRef(u8, None, n=n), y, dy)
+        assert torch.equal(L.grad, got[ns])

@@ -21,7 +21,8 @@ for (h, cin, cout, k, s) in ((84, 4, 32, 3, 2), (41, 32, 32, 3, 2), (20, 32, 32,
     L.backward(x, y, dy)
     dx = torch.empty_like(x)
     t0 = timeit(lambda: check(lib.rlgan_elu_backward(dy.data_ptr(), y.data_ptr(), dz.data_ptr(), dy.numel(), _stream())))
-    t1 = timeit(lambda: check(lib.rlgan_conv_backward_weights(L.conv, x.data_ptr(), dz.data_ptr(), None, L._slabs.data_ptr(), L.n_slabs,
+    sl, ns = L._slab_buffer(B)
+    t1 = timeit(lambda: check(lib.rlgan_conv_backward_weights(L.conv, x.data_ptr(), dz.data_ptr(), None, sl.data_ptr(), ns,
                                                               L.grad.data_ptr(), B, _stream())))
     t2 = timeit(lambda: check(lib.rlgan_conv_backward_input(L.conv, dz.data_ptr(), None, L.canon.data_ptr(), None, dx.data_ptr(), B, _stream())))
     t3 = timeit(lambda: check(lib.rlgan_conv_backward_input(L.conv, dz.data_ptr(), None, L.canon.data_ptr(), L.wdx.data_ptr(), dx.data_ptr(), B, _stream())))
