@@ -85,7 +85,8 @@ int rlgan_build_maps(int kind, int s_dim, int a_dim, int32_t* map_f, int32_t* ma
 /* rows per batch chunk and chunk count the weight-gradient kernel will use for `rows` rows */
 int rlgan_wgrad_chunks(int rows, int32_t* chunk_rows, int32_t* n_chunks);
 
-/* scatter canon -> wf (and wb when non-NULL).  wf/wb must have been zero-filled once. */
+/* scatter canon -> wf (and wb when non-NULL); entries whose offset is -1 are skipped.  wf/wb must have been
+ * zero-filled once. */
 int rlgan_pack_weights(const float* canon, int n_params, const int32_t* map_f, float* wf,
                        const int32_t* map_b, float* wb, void* stream);
 
@@ -418,6 +419,35 @@ int rlgan_dense_forward(const float* x, int ldx, const float* wb, float* y, int 
 int rlgan_dense_backward_input(const float* dz, int lddz, const float* wb, float* dx, int lddx, int m, int k, int n, void* stream);
 int rlgan_dense_backward_weights(const float* x, int ldx, const float* dz, int lddz, float* gwb, int m, int k, int n,
                                  float* slabs, int n_slabs, void* stream);
+
+/* ---- transposed convolutions of the pixel generator's decoder --------------------------------------
+ * tf.layers.conv2d_transpose(net, c_out, k, strides=stride) on NHWC tensors, padding 'valid', the decoder
+ * stack of the reference's full-prediction generator, 1x1x200 -> 3x3x128 -> 8x8x64 -> 19x19x32 -> 42x42x1
+ * with ReLU between the layers (Conv_model.py:457-473).  Parameters in canonical order: TensorFlow's kernel
+ * [k, k, c_out, c_in] row-major, then bias[c_out].  c_in and k*k*c_out must be multiples of 4.
+ * A layer runs as   cols = x2d * Wmat   (rlgan_dense_forward, x2d = [n*h*w][c_in], Wmat = [c_in + 1][kk] with a
+ * zero last row, kk = k*k*c_out; filled from canon through rlgan_deconv_build_map and rlgan_pack_weights),
+ * then rlgan_deconv_place.  Backward: rlgan_deconv_gather (dcols from dY), rlgan_dense_backward_input (dX),
+ * rlgan_dense_backward_weights + rlgan_gather_map (kernel gradient in canonical order), rlgan_column_sums
+ * (bias gradient). */
+typedef struct { int32_t h, w, c_in, c_out, k, stride; } rlgan_deconv_t;
+typedef struct { int32_t h_out, w_out, kk, n_params, wmat_floats, colsum_floats; } rlgan_deconv_geom_t;
+int rlgan_deconv_geometry(const rlgan_deconv_t* deconv, rlgan_deconv_geom_t* out);
+/* host array of n_params int32: offset of every canonical parameter in Wmat, -1 for the bias */
+int rlgan_deconv_build_map(const rlgan_deconv_t* deconv, int32_t* map_w);
+/* y[n, oy, ox, co] = act(bias[co] + sum of cols[(n, iy, ix)][(ky, kx, co)] over oy = iy*stride + ky, ox = ix*stride + kx),
+ * taps added in ascending (ky, kx) order; act_relu 0/1.  n_images <= 65535. */
+int rlgan_deconv_place(const rlgan_deconv_t* deconv, const float* cols, const float* bias, float* y, int n_images,
+                       int act_relu, void* stream);
+/* dcols[(n, iy, ix)][(ky, kx, co)] = dy[n, iy*stride + ky, ix*stride + kx, co] (* ReLU'(y_relu) when y_relu != NULL) */
+int rlgan_deconv_gather(const rlgan_deconv_t* deconv, const float* dy, const float* y_relu, float* dcols, int n_images,
+                        void* stream);
+/* out[c] = sum over rows of dy[r][c] (* ReLU'(y_relu[r][c]) when y_relu != NULL), n_cols <= 256, in a fixed order
+ * (bias gradient of a layer); partial: scratch of 512 * n_cols floats. */
+int rlgan_column_sums(const float* dy, const float* y_relu, int64_t rows, int32_t n_cols, float* partial, float* out,
+                      void* stream);
+/* dst[i] = map[i] >= 0 ? src[map[i]] : 0   (a gradient image back into canonical parameter order) */
+int rlgan_gather_map(const float* src, const int32_t* map, int32_t n, float* dst, void* stream);
 
 #ifdef __cplusplus
 }

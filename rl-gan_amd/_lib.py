@@ -92,6 +92,14 @@ class ConvGeom(C.Structure):
     _fields_ = [(n, _i32) for n in ("h_out", "w_out", "k_len", "n_params", "wfrag_floats", "slab_floats", "wdx_floats")]
 
 
+class Deconv(C.Structure):
+    _fields_ = [(n, _i32) for n in ("h", "w", "c_in", "c_out", "k", "stride")]
+
+
+class DeconvGeom(C.Structure):
+    _fields_ = [(n, _i32) for n in ("h_out", "w_out", "kk", "n_params", "wmat_floats", "colsum_floats")]
+
+
 class Sample(C.Structure):
     _fields_ = [("mt_state", _fp), ("n_pop", C.c_int64), ("n", _i32), ("out_idx", _fp)]
 
@@ -165,6 +173,12 @@ PROTOTYPES = {
     "rlgan_elu_backward": [_vp, _vp, _vp, _i64, _vp],
     "rlgan_conv_backward_input": [C.POINTER(Conv), _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "rlgan_conv_backward_weights": [C.POINTER(Conv), _vp, _vp, _vp, _vp, _i, _vp, _i, _vp],
+    "rlgan_deconv_geometry": [C.POINTER(Deconv), C.POINTER(DeconvGeom)],
+    "rlgan_deconv_build_map": [C.POINTER(Deconv), _vp],
+    "rlgan_deconv_place": [C.POINTER(Deconv), _vp, _vp, _vp, _i, _i, _vp],
+    "rlgan_deconv_gather": [C.POINTER(Deconv), _vp, _vp, _vp, _i, _vp],
+    "rlgan_column_sums": [_vp, _vp, C.c_int64, _i, _vp, _vp, _vp],
+    "rlgan_gather_map": [_vp, _vp, _i, _vp, _vp],
     "rlgan_conv_forward_u8": [C.POINTER(Conv), _vp, C.c_int64, _vp, _f, _vp, _vp, _i, _i, _vp],
     "rlgan_conv_backward_weights_u8": [C.POINTER(Conv), _vp, C.c_int64, _vp, _f, _vp, _vp, _vp, _i, _vp, _i, _vp],
     "rlgan_frames_store": [_vp, C.c_int64, _i, _vp, _i, _vp, _vp],

@@ -9,23 +9,13 @@
 // kernel, so W is the kernel tensor as stored.  Weights live on the device as MFMA B fragments of
 // [W ; b] (the same fragment format the dense layers use), the bias being the row of a constant-1
 // patch element at index K.
+#include "fastdiv.h"
 #include "rlgan_device.h"
 #include "rlgan_host.h"
 
 using namespace rlgan;
 
 namespace {
-
-// n / d for 0 <= n < 2^31 as a multiply-high, an add and a shift (the per-pixel index arithmetic of these kernels
-// would otherwise cost more vector-ALU time than their matrix products): m = floor(2^32 (2^l - d) / d) + 1,
-// l = ceil(log2 d), q = (mulhi(m, n) + n) >> l.
-struct FastDiv { uint32_t m; int l; };
-inline FastDiv make_div(int d) {
-  int l = 0;
-  while ((1u << l) < (uint32_t)d) ++l;
-  return FastDiv{(uint32_t)((((uint64_t)1 << 32) * (((uint64_t)1 << l) - (uint64_t)d)) / (uint64_t)d + 1), l};
-}
-__device__ __forceinline__ int fdiv(int n, FastDiv f) { return (int)((__umulhi(f.m, (uint32_t)n) + (uint32_t)n) >> f.l); }
 
 struct ConvG {
   int H, W, Cin, Cout, k, s;      // input height/width/channels, output channels, kernel size, stride

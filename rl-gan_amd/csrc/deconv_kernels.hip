@@ -1,0 +1,206 @@
+// Transposed convolution (NHWC, 'valid', square kernel) of the pixel generator's decoder, the reference's
+// tf.layers.conv2d_transpose stack 1x1x200 -> 3x3x128 -> 8x8x64 -> 19x19x32 -> 42x42x1 (Conv_model.py:457-473).
+// A layer is a matrix product with every input pixel as a row,
+//   cols[(n, iy, ix)][(ky, kx, co)] = sum_ci x[n, iy, ix, ci] * W[ky, kx, co, ci]        (dense_kernels.hip),
+// followed by the placement kernels of this file: output pixel (oy, ox) collects the entries whose tap lands
+// on it, oy = iy * s + ky, ox = ix * s + kx (a gather in a fixed tap order: no atomics, the same bits every run),
+// plus bias and ReLU.  Backward mirrors it: dcols is the same gather read the other way, the two products with
+// it give dX and dW, and the bias gradient is a two-stage column sum.  gfx950 only.
+#include "fastdiv.h"
+#include "rlgan_device.h"
+#include "rlgan_host.h"
+
+using namespace rlgan;
+
+namespace {
+
+struct DeconvG {
+  int h, w, Co, k, s, Ho, Wo, KK;     // input size, output channels, kernel, stride, output size, k*k*Co
+  FastDiv dU, dCo, dk, ds;            // divisors: units per pixel (see V below), Co, k, s
+};
+
+inline bool make_deconv(const rlgan_deconv_t* d, DeconvG& g) {
+  if (!d || d->h <= 0 || d->w <= 0 || d->c_in <= 0 || d->c_out <= 0 || d->k <= 0 || d->stride <= 0) return false;
+  if (d->c_in % 4 != 0 || (d->k * d->k * d->c_out) % 4 != 0) return false;          // 16-byte rows of the two matrices
+  g.h = d->h; g.w = d->w; g.Co = d->c_out; g.k = d->k; g.s = d->stride;
+  g.Ho = (d->h - 1) * d->stride + d->k; g.Wo = (d->w - 1) * d->stride + d->k;
+  g.KK = d->k * d->k * d->c_out;
+  if ((long long)g.Wo * g.Co > 0x7fffffffll || (long long)g.w * g.KK > 0x7fffffffll) return false;
+  g.dCo = make_div(g.Co); g.dk = make_div(g.k); g.ds = make_div(g.s);
+  return true;
+}
+
+__device__ __forceinline__ float relu_d(float y) { return y > 0.f ? 1.f : 0.f; }
+
+// V = 4 when Co % 4 == 0 (a thread handles four consecutive channels as 16 bytes), else 1.
+template <int V> struct Vec;
+template <> struct Vec<4> {
+  using T = f32x4;
+  static __device__ __forceinline__ T zero() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+  static __device__ __forceinline__ T relu(T v) { return f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)}; }
+  static __device__ __forceinline__ T mask(T d, T y) { return f32x4{d[0] * relu_d(y[0]), d[1] * relu_d(y[1]), d[2] * relu_d(y[2]), d[3] * relu_d(y[3])}; }
+};
+template <> struct Vec<1> {
+  using T = float;
+  static __device__ __forceinline__ T zero() { return 0.f; }
+  static __device__ __forceinline__ T relu(T v) { return fmaxf(v, 0.f); }
+  static __device__ __forceinline__ T mask(T d, T y) { return d * relu_d(y); }
+};
+
+// y[n, oy, ox, c..c+V) = act(bias + sum over the taps (ky, kx) = (oy % s + j*s, ox % s + i*s) that land here,
+// in ascending (ky, kx) order).  grid = (units of a row / 256, Ho, n); a unit = V channels of one pixel.
+template <int V>
+__global__ __launch_bounds__(256) void col2im_kernel(const DeconvG g, const float* __restrict__ cols, const float* __restrict__ bias,
+                                                     float* __restrict__ y, int act) {
+  using T = typename Vec<V>::T;
+  const int cu = g.Co / V;                                   // units per pixel
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= g.Wo * cu) return;
+  const int ox = fdiv(t, g.dU), c = (t - ox * cu) * V;
+  const int oy = blockIdx.y, n = blockIdx.z;
+  const int qy = fdiv(oy, g.ds), ry = oy - qy * g.s, qx = fdiv(ox, g.ds), rx = ox - qx * g.s;
+  T acc = *(const T*)(bias + c);
+  for (int ky = ry, iy = qy; ky < g.k && iy >= 0; ky += g.s, --iy) {
+    if (iy >= g.h) continue;
+    for (int kx = rx, ix = qx; kx < g.k && ix >= 0; kx += g.s, --ix) {
+      if (ix >= g.w) continue;
+      acc += *(const T*)(cols + ((size_t)(n * g.h + iy) * g.w + ix) * g.KK + (ky * g.k + kx) * g.Co + c);
+    }
+  }
+  *(T*)(y + ((size_t)(n * g.Ho + oy) * g.Wo + ox) * g.Co + c) = act ? Vec<V>::relu(acc) : acc;
+}
+
+// dcols[(n, iy, ix)][(ky, kx, c..c+V)] = dy[n, iy*s + ky, ix*s + kx, c..] (* ReLU'(y) when y is given).
+// grid = (units of an input row / 256, h, n); a unit = V channels of one tap of one input pixel.
+template <int V>
+__global__ __launch_bounds__(256) void im2col_kernel(const DeconvG g, const float* __restrict__ dy, const float* __restrict__ yact,
+                                                     float* __restrict__ dcols) {
+  using T = typename Vec<V>::T;
+  const int ku = g.KK / V;                                   // units per input pixel
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= g.w * ku) return;
+  const int ix = fdiv(t, g.dU), e = (t - ix * ku) * V;       // e = (ky*k + kx)*Co + c
+  const int tap = fdiv(e, g.dCo), c = e - tap * g.Co, ky = fdiv(tap, g.dk), kx = tap - ky * g.k;
+  const int iy = blockIdx.y, n = blockIdx.z;
+  const size_t at = ((size_t)(n * g.Ho + iy * g.s + ky) * g.Wo + ix * g.s + kx) * g.Co + c;
+  T d = *(const T*)(dy + at);
+  if (yact) d = Vec<V>::mask(d, *(const T*)(yact + at));
+  *(T*)(dcols + ((size_t)(n * g.h + iy) * g.w + ix) * g.KK + e) = d;
+}
+
+// Column sums of dz[rows][C] (dz = dy * ReLU'(y) when y is given), C <= 256, in two stages with a fixed order:
+// workgroup b adds its contiguous share of the rows (thread = (row phase, column), phases added in order),
+// then one workgroup adds the partial rows in workgroup order.
+__global__ __launch_bounds__(256) void colsum_part_kernel(const float* __restrict__ dy, const float* __restrict__ yact, long long rows,
+                                                          int C, long long rows_per_wg, float* __restrict__ part) {
+  __shared__ float sh[256];
+  const int phases = 256 / C, ph = threadIdx.x / C, c = threadIdx.x - ph * C;
+  const long long r0 = (long long)blockIdx.x * rows_per_wg, r1 = min(rows, r0 + rows_per_wg);
+  float s = 0.f;
+  if (ph < phases) {
+    for (long long r = r0 + ph; r < r1; r += phases) {
+      float d = dy[r * C + c];
+      if (yact) d *= relu_d(yact[r * C + c]);
+      s += d;
+    }
+  }
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x < C) {
+    float tot = 0.f;
+    for (int p = 0; p < phases; ++p) tot += sh[p * C + threadIdx.x];
+    part[(size_t)blockIdx.x * C + threadIdx.x] = tot;
+  }
+}
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int n_part, int C, float* __restrict__ out) {
+  const int c = threadIdx.x;
+  if (c >= C) return;
+  float tot = 0.f;
+  for (int b = 0; b < n_part; ++b) tot += part[(size_t)b * C + c];
+  out[c] = tot;
+}
+
+// dst[i] = map[i] >= 0 ? src[map[i]] : 0
+__global__ void gather_map_kernel(const float* __restrict__ src, const int32_t* __restrict__ map, int n, float* __restrict__ dst) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = map[i] >= 0 ? src[map[i]] : 0.f;
+}
+
+inline int launched() { return (int)hipGetLastError(); }
+constexpr int COLSUM_PARTS = 512;
+
+}  // namespace
+
+extern "C" {
+
+int rlgan_deconv_geometry(const rlgan_deconv_t* d, rlgan_deconv_geom_t* out) {
+  DeconvG g;
+  if (!out) return RLGAN_E_ARG;
+  if (!make_deconv(d, g)) return RLGAN_E_DIMS;
+  out->h_out = g.Ho; out->w_out = g.Wo; out->kk = g.KK;
+  out->n_params = g.KK * d->c_in + d->c_out;
+  out->wmat_floats = (d->c_in + 1) * g.KK;
+  out->colsum_floats = d->c_out <= 256 ? COLSUM_PARTS * d->c_out : 0;
+  return 0;
+}
+
+int rlgan_deconv_build_map(const rlgan_deconv_t* d, int32_t* map_w) {
+  DeconvG g;
+  if (!map_w) return RLGAN_E_ARG;
+  if (!make_deconv(d, g)) return RLGAN_E_DIMS;
+  int p = 0;
+  for (int e = 0; e < g.KK; ++e)                      // e = (ky*k + kx)*Co + co, the kernel tensor's first three axes
+    for (int ci = 0; ci < d->c_in; ++ci) map_w[p++] = ci * g.KK + e;
+  for (int co = 0; co < d->c_out; ++co) map_w[p++] = -1;   // the bias is added after the placement, not by the product
+  return 0;
+}
+
+int rlgan_deconv_place(const rlgan_deconv_t* d, const float* cols, const float* bias, float* y, int n_images, int act_relu,
+                       void* stream) {
+  DeconvG g;
+  if (!make_deconv(d, g)) return RLGAN_E_DIMS;
+  if (!cols || !bias || !y || n_images <= 0 || n_images > 65535 || g.Ho > 65535) return RLGAN_E_ARG;
+  const bool v4 = g.Co % 4 == 0;
+  if (v4 && (((uintptr_t)cols | (uintptr_t)bias | (uintptr_t)y) & 15)) return RLGAN_E_ALIGN;
+  if ((long long)n_images * g.Ho > 0x7fffffffll || (long long)n_images * g.h > 0x7fffffffll) return RLGAN_E_ALIGN;
+  const int units = g.Wo * (g.Co / (v4 ? 4 : 1));
+  g.dU = make_div(g.Co / (v4 ? 4 : 1));
+  const dim3 grid(cdiv(units, 256), g.Ho, n_images), block(256);
+  if (v4) hipLaunchKernelGGL(col2im_kernel<4>, grid, block, 0, (hipStream_t)stream, g, cols, bias, y, act_relu);
+  else hipLaunchKernelGGL(col2im_kernel<1>, grid, block, 0, (hipStream_t)stream, g, cols, bias, y, act_relu);
+  return launched();
+}
+
+int rlgan_deconv_gather(const rlgan_deconv_t* d, const float* dy, const float* y_relu, float* dcols, int n_images, void* stream) {
+  DeconvG g;
+  if (!make_deconv(d, g)) return RLGAN_E_DIMS;
+  if (!dy || !dcols || n_images <= 0 || n_images > 65535 || g.h > 65535) return RLGAN_E_ARG;
+  const bool v4 = g.Co % 4 == 0;
+  if (v4 && (((uintptr_t)dy | (uintptr_t)y_relu | (uintptr_t)dcols) & 15)) return RLGAN_E_ALIGN;
+  if ((long long)n_images * g.Ho > 0x7fffffffll || (long long)n_images * g.h > 0x7fffffffll) return RLGAN_E_ALIGN;
+  const int units = g.w * (g.KK / (v4 ? 4 : 1));
+  g.dU = make_div(g.KK / (v4 ? 4 : 1));
+  const dim3 grid(cdiv(units, 256), g.h, n_images), block(256);
+  if (v4) hipLaunchKernelGGL(im2col_kernel<4>, grid, block, 0, (hipStream_t)stream, g, dy, y_relu, dcols);
+  else hipLaunchKernelGGL(im2col_kernel<1>, grid, block, 0, (hipStream_t)stream, g, dy, y_relu, dcols);
+  return launched();
+}
+
+int rlgan_column_sums(const float* dy, const float* y_relu, int64_t rows, int32_t n_cols, float* partial, float* out, void* stream) {
+  if (!dy || !partial || !out || rows <= 0 || n_cols <= 0) return RLGAN_E_ARG;
+  if (n_cols > 256) return RLGAN_E_DIMS;
+  const long long per = ((long long)rows + COLSUM_PARTS - 1) / COLSUM_PARTS;
+  const int parts = (int)(((long long)rows + per - 1) / per);
+  hipLaunchKernelGGL(colsum_part_kernel, dim3(parts), dim3(256), 0, (hipStream_t)stream, dy, y_relu, (long long)rows, n_cols, per, partial);
+  if (const int rc = launched()) return rc;
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, parts, n_cols, out);
+  return launched();
+}
+
+int rlgan_gather_map(const float* src, const int32_t* map, int32_t n, float* dst, void* stream) {
+  if (!src || !map || !dst || n <= 0) return RLGAN_E_ARG;
+  hipLaunchKernelGGL(gather_map_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, src, map, n, dst);
+  return launched();
+}
+
+}  // extern "C"

@@ -636,7 +636,8 @@ __global__ void pack_kernel(const float* __restrict__ canon, int n, const int32_
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n) return;
   const float w = canon[p];
-  wf[map_f[p]] = w;
+  const int of = map_f[p];
+  if (of >= 0) wf[of] = w;
   if (wb) { const int ob = map_b[p]; if (ob >= 0) wb[ob] = w; }
 }
 
