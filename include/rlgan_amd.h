@@ -209,7 +209,8 @@ typedef struct {
 } rlgan_reduce_job_t;
 int rlgan_grad_reduce(const rlgan_reduce_job_t* jobs, int n_jobs, void* stream);
 
-/* One optimizer step per job, writing canon and its fragment images.
+/* One optimizer step per job, writing canon and its fragment images (wf may be NULL for a layer that is used
+ * from canon alone; map offsets of -1 are skipped).
  *  opt 0: tf.train.RMSPropOptimizer (DDPG.py:112,148): ms <- decay*ms+(1-decay)*g^2 (ms = slot0, starts
  *         at 1, decay = beta1), w <- w - lr*g/sqrt(ms+eps);
  *  opt 1: tf.train.AdamOptimizer (Curious_GAN.py:45,142): m = slot0, v = slot1, lr_t =
@@ -448,6 +449,18 @@ int rlgan_column_sums(const float* dy, const float* y_relu, int64_t rows, int32_
                       void* stream);
 /* dst[i] = map[i] >= 0 ? src[map[i]] : 0   (a gradient image back into canonical parameter order) */
 int rlgan_gather_map(const float* src, const int32_t* map, int32_t n, float* dst, void* stream);
+
+/* ---- glue of the pixel generator's training step (Conv_model.py:437-456,522-541) ------------------------
+ * dz = dy * ReLU'(y)   (tf.nn.relu after the generator's first layer, Conv_model.py:455) */
+int rlgan_relu_backward(const float* dy, const float* y, float* dz, int64_t n, void* stream);
+/* dst[r][0..n_copy) = src[r][0..n_copy), dst[r][n_copy..n_copy+n_zero) = 0 for r < rows: concatenation of
+ * [features, action] rows (Conv_model.py:452), channel padding of the generated 1-channel image to the 4
+ * channels the convolution kernels take, and the way back (n_zero = 0). */
+int rlgan_copy_cols(const float* src, int ld_src, float* dst, int ld_dst, int64_t rows, int n_copy, int n_zero, void* stream);
+/* tf.reduce_mean(tf.squared_difference(fake, real)) (Conv_model.py:527): parts[b] = sum of (fake-real)^2 over
+ * workgroup b's 4096 elements (n_parts = ceil(n / 4096); the loss is rlgan_sum_parts(parts, n_parts, 1, 1/n)),
+ * dfake = 2 (fake - real) / n when non-NULL. */
+int rlgan_mse(const float* fake, const float* real, int64_t n, float* parts, float* dfake, void* stream);
 
 #ifdef __cplusplus
 }

@@ -179,6 +179,9 @@ PROTOTYPES = {
     "rlgan_deconv_gather": [C.POINTER(Deconv), _vp, _vp, _vp, _i, _vp],
     "rlgan_column_sums": [_vp, _vp, C.c_int64, _i, _vp, _vp, _vp],
     "rlgan_gather_map": [_vp, _vp, _i, _vp, _vp],
+    "rlgan_relu_backward": [_vp, _vp, _vp, C.c_int64, _vp],
+    "rlgan_copy_cols": [_vp, _i, _vp, _i, C.c_int64, _i, _i, _vp],
+    "rlgan_mse": [_vp, _vp, C.c_int64, _vp, _vp, _vp],
     "rlgan_conv_forward_u8": [C.POINTER(Conv), _vp, C.c_int64, _vp, _f, _vp, _vp, _i, _i, _vp],
     "rlgan_conv_backward_weights_u8": [C.POINTER(Conv), _vp, C.c_int64, _vp, _f, _vp, _vp, _vp, _i, _vp, _i, _vp],
     "rlgan_frames_store": [_vp, C.c_int64, _i, _vp, _i, _vp, _vp],

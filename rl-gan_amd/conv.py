@@ -175,21 +175,28 @@ class DenseLayer:
         f = self.canon.cpu().numpy()
         return f[:self.k * self.n].reshape(self.k, self.n), f[self.k * self.n:]
 
-    def forward(self, x: torch.Tensor, act: bool = True) -> torch.Tensor:
+    @staticmethod
+    def _act_code(act) -> int:
+        """True / "elu": ELU (the encoders' head); "relu": ReLU (the pixel generator's first layer); False / None: linear."""
+        return {True: 1, "elu": 1, "relu": 2, False: 0, None: 0}[act]
+
+    def forward(self, x: torch.Tensor, act=True) -> torch.Tensor:
         assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.ndim == 2 and x.shape[1] == self.k
         y = torch.empty((x.shape[0], self.n), dtype=torch.float32, device=x.device)
         sc, ns = self._slabs(x.shape[0], self.k + 1)
         check(lib.rlgan_dense_forward(x.data_ptr(), self.k, self.canon.data_ptr(), y.data_ptr(), self.n, x.shape[0], self.k, self.n,
-                                      1 if act else 0, None if sc is None else sc.data_ptr(), ns, _stream()), "rlgan_dense_forward")
+                                      self._act_code(act), None if sc is None else sc.data_ptr(), ns, _stream()), "rlgan_dense_forward")
         return y
 
-    def backward(self, x: torch.Tensor, y: torch.Tensor, dy: torch.Tensor, need_dx: bool = True, act: bool = True):
+    def backward(self, x: torch.Tensor, y: torch.Tensor, dy: torch.Tensor, need_dx: bool = True, act=True):
         """Gradients of this layer: fills self.grad (kernel then bias), returns dx or None."""
         m = x.shape[0]
         dz = dy
-        if act:
+        code = self._act_code(act)
+        if code:
             dz = torch.empty_like(dy)
-            check(lib.rlgan_elu_backward(dy.data_ptr(), y.data_ptr(), dz.data_ptr(), dy.numel(), _stream()), "rlgan_elu_backward")
+            fn, name = (lib.rlgan_elu_backward, "rlgan_elu_backward") if code == 1 else (lib.rlgan_relu_backward, "rlgan_relu_backward")
+            check(fn(dy.data_ptr(), y.data_ptr(), dz.data_ptr(), dy.numel(), _stream()), name)
         sc, ns = self._slabs(self.k + 1, m)
         check(lib.rlgan_dense_backward_weights(x.data_ptr(), self.k, dz.data_ptr(), self.n, self.grad.data_ptr(), m, self.k, self.n,
                                                None if sc is None else sc.data_ptr(), ns, _stream()), "rlgan_dense_backward_weights")

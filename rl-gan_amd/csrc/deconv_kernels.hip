@@ -126,6 +126,50 @@ __global__ void gather_map_kernel(const float* __restrict__ src, const int32_t* 
   if (i < n) dst[i] = map[i] >= 0 ? src[map[i]] : 0.f;
 }
 
+__global__ void relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dz, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dz[i] = dy[i] * relu_d(y[i]);
+}
+
+// one thread per destination element; blockIdx.y walks the rows in steps of gridDim.y
+__global__ void copy_cols_kernel(const float* __restrict__ src, int ld_src, float* __restrict__ dst, int ld_dst, long long rows,
+                                 int n_copy, int n_zero) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n_copy + n_zero) return;
+  for (long long r = blockIdx.y; r < rows; r += gridDim.y) dst[r * ld_dst + c] = c < n_copy ? src[r * ld_src + c] : 0.f;
+}
+// narrow rows (n_copy + n_zero <= 4: the channel padding): one thread per row
+__global__ void copy_cols_narrow_kernel(const float* __restrict__ src, int ld_src, float* __restrict__ dst, int ld_dst, long long rows,
+                                        int n_copy, int n_zero) {
+  const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  for (int c = 0; c < n_copy + n_zero; ++c) dst[r * ld_dst + c] = c < n_copy ? src[r * ld_src + c] : 0.f;
+}
+
+constexpr int MSE_PER_WG = 4096;
+__global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ fake, const float* __restrict__ real, long long n, float inv_n2,
+                                                  float* __restrict__ parts, float* __restrict__ dfake) {
+  __shared__ float sh[256];
+  const long long i0 = (long long)blockIdx.x * MSE_PER_WG;
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < MSE_PER_WG / 256; ++j) {
+    const long long i = i0 + j * 256 + threadIdx.x;
+    if (i < n) {
+      const float d = fake[i] - real[i];
+      s += d * d;
+      if (dfake) dfake[i] = d * inv_n2;
+    }
+  }
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {                       // fixed tree: the same bits every run
+    if (threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) parts[blockIdx.x] = sh[0];
+}
+
 inline int launched() { return (int)hipGetLastError(); }
 constexpr int COLSUM_PARTS = 512;
 
@@ -200,6 +244,36 @@ int rlgan_column_sums(const float* dy, const float* y_relu, int64_t rows, int32_
 int rlgan_gather_map(const float* src, const int32_t* map, int32_t n, float* dst, void* stream) {
   if (!src || !map || !dst || n <= 0) return RLGAN_E_ARG;
   hipLaunchKernelGGL(gather_map_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, src, map, n, dst);
+  return launched();
+}
+
+int rlgan_relu_backward(const float* dy, const float* y, float* dz, int64_t n, void* stream) {
+  if (!dy || !y || !dz || n <= 0) return RLGAN_E_ARG;
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dy, y, dz, (size_t)n);
+  return launched();
+}
+
+int rlgan_copy_cols(const float* src, int ld_src, float* dst, int ld_dst, int64_t rows, int n_copy, int n_zero, void* stream) {
+  if (!dst || rows <= 0 || n_copy < 0 || n_zero < 0 || n_copy + n_zero <= 0 || (n_copy > 0 && !src)) return RLGAN_E_ARG;
+  if (ld_dst < n_copy + n_zero || (n_copy > 0 && ld_src < n_copy)) return RLGAN_E_ALIGN;
+  const int nc = n_copy + n_zero;
+  if (nc <= 4) {
+    hipLaunchKernelGGL(copy_cols_narrow_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       src, ld_src, dst, ld_dst, (long long)rows, n_copy, n_zero);
+  } else {
+    const unsigned gy = (unsigned)std::min<int64_t>(rows, 4096);
+    hipLaunchKernelGGL(copy_cols_kernel, dim3(cdiv(nc, 256), gy), dim3(256), 0, (hipStream_t)stream,
+                       src, ld_src, dst, ld_dst, (long long)rows, n_copy, n_zero);
+  }
+  return launched();
+}
+
+int rlgan_mse(const float* fake, const float* real, int64_t n, float* parts, float* dfake, void* stream) {
+  if (!fake || !real || !parts || n <= 0) return RLGAN_E_ARG;
+  const long long blocks = (n + MSE_PER_WG - 1) / MSE_PER_WG;
+  if (blocks > 0x7fffffffll) return RLGAN_E_ARG;
+  hipLaunchKernelGGL(mse_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, fake, real, (long long)n,
+                     (float)(2.0 / (double)n), parts, dfake);
   return launched();
 }
 

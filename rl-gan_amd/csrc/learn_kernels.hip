@@ -599,14 +599,14 @@ __global__ __launch_bounds__(256) void apply_kernel(const ApplyArgs A) {
     w = J.canon[p] - lr_t * m / (sqrtf(v) + J.eps);
   }
   J.canon[p] = w;
-  const int of = J.map_f[p];
-  J.wf[of] = w;
+  const int of = J.wf ? J.map_f[p] : -1;                   // -1: this parameter has no place in the image (or there is no image)
+  if (of >= 0) J.wf[of] = w;
   if (J.wb) { const int ob = J.map_b[p]; if (ob >= 0) J.wb[ob] = w; }
   if (J.target_canon && (!J.counter || ((J.counter[0] - 1) % J.period) == 0)) {
     // hard copy (tau = 1, DDPG.py:99-101,176-178) or Polyak average
     const float tw = J.tau == 1.f ? w : J.tau * w + (1.f - J.tau) * J.target_canon[p];
     J.target_canon[p] = tw;
-    J.target_wf[of] = tw;
+    if (of >= 0) J.target_wf[of] = tw;
   }
 }
 
@@ -628,7 +628,8 @@ __global__ void target_update_kernel(float* __restrict__ tc, const float* __rest
   if (p >= n) return;
   const float w = tau == 1.f ? ec[p] : tau * ec[p] + (1.f - tau) * tc[p];
   tc[p] = w;
-  twf[map_f[p]] = w;
+  const int of = map_f[p];
+  if (of >= 0) twf[of] = w;
 }
 
 __global__ void pack_kernel(const float* __restrict__ canon, int n, const int32_t* __restrict__ map_f,
@@ -829,7 +830,8 @@ int rlgan_apply(const rlgan_apply_job_t* jobs, int n_jobs, void* stream) {
   int b = 0;
   for (int i = 0; i < n_jobs; ++i) {
     const rlgan_apply_job_t& J = jobs[i];
-    if (!J.canon || (!J.grad && !J.reduce) || !J.slot0 || !J.map_f || !J.wf || J.n_params <= 0 || (J.wb && !J.map_b)) return RLGAN_E_ARG;
+    if (!J.canon || (!J.grad && !J.reduce) || !J.slot0 || (J.wf && !J.map_f) || J.n_params <= 0 || (J.wb && !J.map_b)) return RLGAN_E_ARG;
+    if (!J.wf && J.target_canon) return RLGAN_E_ARG;
     if (J.opt != 0 && J.opt != 1) return RLGAN_E_ARG;
     if (J.opt == 1 && (!J.slot1 || !J.step)) return RLGAN_E_ARG;
     if (J.target_canon && (!J.target_wf || (J.counter && J.period <= 0))) return RLGAN_E_ARG;
