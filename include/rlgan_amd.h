@@ -461,6 +461,15 @@ int rlgan_copy_cols(const float* src, int ld_src, float* dst, int ld_dst, int64_
  * workgroup b's 4096 elements (n_parts = ceil(n / 4096); the loss is rlgan_sum_parts(parts, n_parts, 1, 1/n)),
  * dfake = 2 (fake - real) / n when non-NULL. */
 int rlgan_mse(const float* fake, const float* real, int64_t n, float* parts, float* dfake, void* stream);
+/* dst[r][0..n) += src[r][0..n) for r < rows (the two uses of phis in the pixel discriminator, Conv_model.py:183-191) */
+int rlgan_add_cols(const float* src, int ld_src, float* dst, int ld_dst, int64_t rows, int n, void* stream);
+/* D_loss_real / D_loss_fake of the pixel discriminator (tf.nn.sigmoid_cross_entropy_with_logits + reduce_mean,
+ * Conv_model.py:207-214) on column 0 of logits[n_real + n_fake][ld], real rows first (label 1), fake rows after
+ * (label 0): loss[0] = mean over the real rows, loss[1] = mean over the fake rows; when dlogits is non-NULL,
+ * dlogits[r][0] = (sigmoid - label) / (rows of r's half) and its other ld - 1 columns are zeroed. */
+int rlgan_sigmoid_ce(const float* logits, int ld, int n_real, int n_fake, float* loss, float* dlogits, void* stream);
+/* out[r] = 1 - sigmoid(logits[r][0]), r < n: the intrinsic reward `1 - D_fake` (Conv_model.py:294,298) */
+int rlgan_one_minus_sigmoid(const float* logits, int ld, int n, float* out, void* stream);
 
 #ifdef __cplusplus
 }

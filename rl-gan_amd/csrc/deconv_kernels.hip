@@ -170,6 +170,47 @@ __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ fake
   if (threadIdx.x == 0) parts[blockIdx.x] = sh[0];
 }
 
+__global__ void add_cols_kernel(const float* __restrict__ src, int ld_src, float* __restrict__ dst, int ld_dst, long long rows, int n) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n) return;
+  for (long long r = blockIdx.y; r < rows; r += gridDim.y) dst[r * ld_dst + c] += src[r * ld_src + c];
+}
+
+// tf.nn.sigmoid_cross_entropy_with_logits on column 0 of logits[n_real + n_fake][ld]: labels 1 for the first
+// n_real rows and 0 for the rest; loss[0] = mean over the real rows, loss[1] = mean over the fake rows;
+// dlogits[r][0] = (sigmoid(x) - label) / (rows of r's half), its other columns zero.  One workgroup, fixed order.
+__global__ __launch_bounds__(256) void sigmoid_ce_kernel(const float* __restrict__ logits, int ld, int n_real, int n_fake,
+                                                         float* __restrict__ loss, float* __restrict__ dlogits) {
+  __shared__ float sh[2][256];
+  float s[2] = {0.f, 0.f};
+  for (int r = threadIdx.x; r < n_real + n_fake; r += 256) {
+    const float x = logits[(size_t)r * ld];
+    const bool real = r < n_real;
+    const float z = real ? 1.f : 0.f;
+    s[real ? 0 : 1] += fmaxf(x, 0.f) - x * z + log1pf(expf(-fabsf(x)));
+    if (dlogits) {
+      const float sig = 1.f / (1.f + expf(-x));
+      dlogits[(size_t)r * ld] = (sig - z) / (float)(real ? n_real : n_fake);
+      for (int c = 1; c < ld; ++c) dlogits[(size_t)r * ld + c] = 0.f;
+    }
+  }
+  sh[0][threadIdx.x] = s[0]; sh[1][threadIdx.x] = s[1];
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (threadIdx.x < w) { sh[0][threadIdx.x] += sh[0][threadIdx.x + w]; sh[1][threadIdx.x] += sh[1][threadIdx.x + w]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    loss[0] = n_real > 0 ? sh[0][0] / (float)n_real : 0.f;
+    loss[1] = n_fake > 0 ? sh[1][0] / (float)n_fake : 0.f;
+  }
+}
+
+__global__ void one_minus_sigmoid_kernel(const float* __restrict__ logits, int ld, int n, float* __restrict__ out) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < n) out[r] = 1.f - 1.f / (1.f + expf(-logits[(size_t)r * ld]));
+}
+
 inline int launched() { return (int)hipGetLastError(); }
 constexpr int COLSUM_PARTS = 512;
 
@@ -265,6 +306,26 @@ int rlgan_copy_cols(const float* src, int ld_src, float* dst, int ld_dst, int64_
     hipLaunchKernelGGL(copy_cols_kernel, dim3(cdiv(nc, 256), gy), dim3(256), 0, (hipStream_t)stream,
                        src, ld_src, dst, ld_dst, (long long)rows, n_copy, n_zero);
   }
+  return launched();
+}
+
+int rlgan_add_cols(const float* src, int ld_src, float* dst, int ld_dst, int64_t rows, int n, void* stream) {
+  if (!src || !dst || rows <= 0 || n <= 0) return RLGAN_E_ARG;
+  if (ld_src < n || ld_dst < n) return RLGAN_E_ALIGN;
+  const unsigned gy = (unsigned)std::min<int64_t>(rows, 4096);
+  hipLaunchKernelGGL(add_cols_kernel, dim3(cdiv(n, 256), gy), dim3(256), 0, (hipStream_t)stream, src, ld_src, dst, ld_dst, (long long)rows, n);
+  return launched();
+}
+
+int rlgan_sigmoid_ce(const float* logits, int ld, int n_real, int n_fake, float* loss, float* dlogits, void* stream) {
+  if (!logits || !loss || ld <= 0 || n_real < 0 || n_fake < 0 || n_real + n_fake <= 0) return RLGAN_E_ARG;
+  hipLaunchKernelGGL(sigmoid_ce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, ld, n_real, n_fake, loss, dlogits);
+  return launched();
+}
+
+int rlgan_one_minus_sigmoid(const float* logits, int ld, int n, float* out, void* stream) {
+  if (!logits || !out || ld <= 0 || n <= 0) return RLGAN_E_ARG;
+  hipLaunchKernelGGL(one_minus_sigmoid_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, logits, ld, n, out);
   return launched();
 }
 

@@ -139,7 +139,141 @@ class PixelGenerator:
         dcode = self.decoder.backward(dimg)
         self.l1.backward(self._x, self._h1, dcode.contiguous(), need_dx=False, act="relu")
         self.step.add_(1)
-        jobs = [o.job(self.step, self.lr if lr is None else lr) for o in self._opt]
-        for i in range(0, len(jobs), 4):
-            launch_apply(jobs[i:i + 4])
+        _adam_jobs(self._opt, self.step, self.lr if lr is None else lr)
         return self.loss_out
+
+
+N_L3 = 10                                                       # Conv_model.py:256
+
+
+def _adam_for(layer) -> _Adam:
+    """Adam slots for a dense layer (used from canon alone), a decoder layer or a convolution (canon + images)."""
+    if hasattr(layer, "wfrag"):
+        o = _Adam(layer, layer.map_f, layer.wfrag)
+        o.map_b, o.image_b = layer.map_dx, layer.wdx
+        return o
+    if hasattr(layer, "wmat"):
+        return _Adam(layer, layer.map_w, layer.wmat)
+    return _Adam(layer)
+
+
+def _adam_jobs(opts, step: torch.Tensor, lr: float):
+    jobs = []
+    for o in opts:
+        j = o.job(step, lr)
+        if getattr(o, "image_b", None) is not None:
+            j.map_b, j.wb = o.map_b.data_ptr(), o.image_b.data_ptr()
+        jobs.append(j)
+    for i in range(0, len(jobs), 4):
+        launch_apply(jobs[i:i + 4])
+
+
+class PixelDiscriminator:
+    """`Discriminator` of the pixel variant in 'full_prediction' mode (Conv_model.py:159-340, wiring
+    Curious_GAN_mario.py:340-346):
+
+        D(h, a, g) = sigmoid(dense1(relu(dense10(relu(h w1_s + g w1_G + a w1_a + b1)))))          Conv_model.py:225-268
+        D_real on (phis(s), a, observation = E(single s')), D_fake on (phis(s), a, fake_observation = E(image))
+        D_loss = mean CE(real, 1) + mean CE(fake, 0); Adam on the discriminator's, the state encoder's and the
+        single-frame encoder's variables (Conv_model.py:192-194,207-223).
+
+    The generated image enters `learn` as data (Conv_model.py:275-276), so nothing flows to the generator.  The
+    10- and 1-unit layers are kept 12 and 4 wide (16-byte rows); the extra units have zero weights and receive
+    zero gradients."""
+
+    def __init__(self, a_dim: int, learning_rate: float, state_encoder: ConvEncoder, obs_encoder: ConvEncoder,
+                 rng: Optional[np.random.RandomState] = None, params: Optional[dict] = None):
+        rng = rng or np.random.RandomState()
+        self.h_dim, self.obs_dim, self.a_dim, self.lr = state_encoder.features, obs_encoder.features, a_dim, learning_rate
+        k_in = self.h_dim + self.obs_dim + a_dim
+        self.k_pad = (k_in + 3) // 4 * 4
+        if params is None:                                      # xavier_initializer, biases 0.001 (Conv_model.py:231-232)
+            xav = lambda i, o: rng.uniform(-np.sqrt(6.0 / (i + o)), np.sqrt(6.0 / (i + o)), (i, o))
+            params = dict(w1_G=xav(self.obs_dim, N_L1), w1_s=xav(self.h_dim, N_L1), w1_a=xav(a_dim, N_L1), b1=np.full(N_L1, 0.001),
+                          w3=xav(N_L1, N_L3), b3=np.full(N_L3, 0.001), w2=xav(N_L3, 1), b2=np.full(1, 0.001))
+        k1 = np.zeros((self.k_pad, N_L1))
+        k1[:self.h_dim], k1[self.h_dim:self.h_dim + self.obs_dim] = params["w1_s"], params["w1_G"]
+        k1[self.h_dim + self.obs_dim:k_in] = params["w1_a"]
+        k3, b3 = np.zeros((N_L1, 12)), np.zeros(12)
+        k3[:, :N_L3], b3[:N_L3] = params["w3"], np.asarray(params["b3"]).reshape(-1)
+        k2, b2 = np.zeros((12, 4)), np.zeros(4)
+        k2[:N_L3, :1], b2[:1] = params["w2"], np.asarray(params["b2"]).reshape(-1)
+        self.l1 = DenseLayer(self.k_pad, N_L1, kernel=k1, bias=np.asarray(params["b1"]).reshape(-1))
+        self.l3 = DenseLayer(N_L1, 12, kernel=k3, bias=b3)
+        self.l2 = DenseLayer(12, 4, kernel=k2, bias=b2)
+        self.state_encoder, self.obs_encoder = state_encoder, obs_encoder
+        self.step = torch.zeros(1, dtype=torch.int32, device=device())
+        self.losses = torch.zeros(2, dtype=torch.float32, device=device())     # D_loss_real, D_loss_fake
+        trained = [self.l1, self.l3, self.l2] + state_encoder.layers + [state_encoder.head] + obs_encoder.layers + [obs_encoder.head]
+        self._opt = [_adam_for(L) for L in trained]
+
+    def _pad4(self, img1: torch.Tensor) -> torch.Tensor:
+        n, h, w, _ = img1.shape
+        out = torch.empty((n, h, w, 4), dtype=torch.float32, device=img1.device)
+        check(lib.rlgan_copy_cols(img1.data_ptr(), 1, out.data_ptr(), 4, n * h * w, 1, 3, _stream()), "rlgan_copy_cols")
+        return out
+
+    def _rows(self, phis: torch.Tensor, feats: torch.Tensor, a: torch.Tensor, copies: int) -> torch.Tensor:
+        """[copies * n, k_pad] rows [phis, feats, a, 0]; phis and a repeat for every copy, feats is [copies * n, obs_dim]."""
+        n = phis.shape[0]
+        x = torch.empty((copies * n, self.k_pad), dtype=torch.float32, device=phis.device)
+        pad = self.k_pad - self.h_dim - self.obs_dim - self.a_dim
+        for c in range(copies):
+            base = x.data_ptr() + 4 * c * n * self.k_pad
+            check(lib.rlgan_copy_cols(phis.data_ptr(), phis.stride(0), base, self.k_pad, n, self.h_dim, 0, _stream()), "rlgan_copy_cols")
+            check(lib.rlgan_copy_cols(a.data_ptr(), a.stride(0), base + 4 * (self.h_dim + self.obs_dim), self.k_pad, n, self.a_dim, pad,
+                                      _stream()), "rlgan_copy_cols")
+        check(lib.rlgan_copy_cols(feats.data_ptr(), feats.stride(0), x.data_ptr() + 4 * self.h_dim, self.k_pad, copies * n, self.obs_dim, 0,
+                                  _stream()), "rlgan_copy_cols")
+        return x
+
+    def _net(self, x: torch.Tensor):
+        h1 = self.l1.forward(x, act="relu")
+        h3 = self.l3.forward(h1, act="relu")
+        return h1, h3, self.l2.forward(h3, act=False)
+
+    def determine_batch(self, s, a: torch.Tensor, g_image: torch.Tensor) -> torch.Tensor:
+        """1 - D_fake for a batch, the intrinsic reward (Conv_model.py:296-303): [n, 1]."""
+        phis = self.state_encoder.forward(s)
+        fobs = self.obs_encoder.forward(self._pad4(g_image.contiguous()))
+        _, _, logits = self._net(self._rows(phis, fobs, a.contiguous(), 1))
+        out = torch.empty((logits.shape[0], 1), dtype=torch.float32, device=logits.device)
+        check(lib.rlgan_one_minus_sigmoid(logits.data_ptr(), 4, logits.shape[0], out.data_ptr(), _stream()), "rlgan_one_minus_sigmoid")
+        return out
+
+    def _forward_pair(self, s, a, single_s_next, g_image):
+        n = a.shape[0]
+        phis = self.state_encoder.forward(s)
+        frames = torch.cat([single_s_next, g_image], 0).contiguous()          # real rows first, fake rows after
+        feats = self.obs_encoder.forward(self._pad4(frames))
+        x = self._rows(phis, feats, a.contiguous(), 2)
+        h1, h3, logits = self._net(x)
+        return n, x, h1, h3, logits
+
+    def eval(self, g_image, single_s_next, s, a) -> float:
+        """D_loss (Conv_model.py:328-340)."""
+        n, _, _, _, logits = self._forward_pair(s, a, single_s_next, g_image)
+        check(lib.rlgan_sigmoid_ce(logits.data_ptr(), 4, n, n, self.losses.data_ptr(), None, _stream()), "rlgan_sigmoid_ce")
+        real, fake = self.losses.tolist()
+        return real + fake
+
+    def learn(self, g_image, single_s_next, s, a, lr: Optional[float] = None) -> torch.Tensor:
+        """One Adam step (Conv_model.py:270-281); returns (D_loss_real, D_loss_fake) before the step (device)."""
+        n, x, h1, h3, logits = self._forward_pair(s, a, single_s_next, g_image)
+        dlogits = torch.empty_like(logits)
+        check(lib.rlgan_sigmoid_ce(logits.data_ptr(), 4, n, n, self.losses.data_ptr(), dlogits.data_ptr(), _stream()), "rlgan_sigmoid_ce")
+        dh3 = self.l2.backward(h3, logits, dlogits, act=False)
+        dh1 = self.l3.backward(h1, h3, dh3, act="relu")
+        dx = self.l1.backward(x, h1, dh1, act="relu")
+        dfeats = torch.empty((2 * n, self.obs_dim), dtype=torch.float32, device=dx.device)
+        check(lib.rlgan_copy_cols(dx.data_ptr() + 4 * self.h_dim, self.k_pad, dfeats.data_ptr(), self.obs_dim, 2 * n, self.obs_dim, 0,
+                                  _stream()), "rlgan_copy_cols")
+        dphis = torch.empty((n, self.h_dim), dtype=torch.float32, device=dx.device)
+        check(lib.rlgan_copy_cols(dx.data_ptr(), self.k_pad, dphis.data_ptr(), self.h_dim, n, self.h_dim, 0, _stream()), "rlgan_copy_cols")
+        check(lib.rlgan_add_cols(dx.data_ptr() + 4 * n * self.k_pad, self.k_pad, dphis.data_ptr(), self.h_dim, n, self.h_dim, _stream()),
+              "rlgan_add_cols")
+        self.obs_encoder.backward(dfeats)
+        self.state_encoder.backward(dphis)
+        self.step.add_(1)
+        _adam_jobs(self._opt, self.step, self.lr if lr is None else lr)
+        return self.losses
