@@ -113,11 +113,30 @@ __global__ __launch_bounds__(256) void colsum_part_kernel(const float* __restric
   }
 }
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int n_part, int C, float* __restrict__ out) {
-  const int c = threadIdx.x;
-  if (c >= C) return;
+  // thread = (phase, column): a phase adds every `phases`-th partial row in order, eight loads in flight at a time
+  // (one load per addition would be a chain of memory latencies), then the phases are added in order
+  __shared__ float sh[256];
+  const int phases = 256 / C, ph = threadIdx.x / C, c = threadIdx.x - ph * C;
   float tot = 0.f;
-  for (int b = 0; b < n_part; ++b) tot += part[(size_t)b * C + c];
-  out[c] = tot;
+  if (ph < phases) {
+    for (int b0 = ph; b0 < n_part; b0 += 8 * phases) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int b = b0 + j * phases;
+        v[j] = b < n_part ? part[(size_t)b * C + c] : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) tot += v[j];
+    }
+  }
+  sh[threadIdx.x] = tot;
+  __syncthreads();
+  if (threadIdx.x < C) {
+    float t = 0.f;
+    for (int p = 0; p < phases; ++p) t += sh[p * C + threadIdx.x];
+    out[threadIdx.x] = t;
+  }
 }
 
 // dst[i] = map[i] >= 0 ? src[map[i]] : 0

@@ -241,9 +241,10 @@ class PixelDiscriminator:
         check(lib.rlgan_one_minus_sigmoid(logits.data_ptr(), 4, logits.shape[0], out.data_ptr(), _stream()), "rlgan_one_minus_sigmoid")
         return out
 
-    def _forward_pair(self, s, a, single_s_next, g_image):
+    def _forward_pair(self, s, a, single_s_next, g_image, phis=None):
         n = a.shape[0]
-        phis = self.state_encoder.forward(s)
+        if phis is None:                                         # else: the state encoder still holds this batch's activations
+            phis = self.state_encoder.forward(s)
         frames = torch.cat([single_s_next, g_image], 0).contiguous()          # real rows first, fake rows after
         feats = self.obs_encoder.forward(self._pad4(frames))
         x = self._rows(phis, feats, a.contiguous(), 2)
@@ -257,9 +258,10 @@ class PixelDiscriminator:
         real, fake = self.losses.tolist()
         return real + fake
 
-    def learn(self, g_image, single_s_next, s, a, lr: Optional[float] = None) -> torch.Tensor:
-        """One Adam step (Conv_model.py:270-281); returns (D_loss_real, D_loss_fake) before the step (device)."""
-        n, x, h1, h3, logits = self._forward_pair(s, a, single_s_next, g_image)
+    def learn(self, g_image, single_s_next, s, a, lr: Optional[float] = None, phis: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """One Adam step (Conv_model.py:270-281); returns (D_loss_real, D_loss_fake) before the step (device).
+        phis: features of `s` from a forward pass of the state encoder that is still its latest one (saves the pass)."""
+        n, x, h1, h3, logits = self._forward_pair(s, a, single_s_next, g_image, phis)
         dlogits = torch.empty_like(logits)
         check(lib.rlgan_sigmoid_ce(logits.data_ptr(), 4, n, n, self.losses.data_ptr(), dlogits.data_ptr(), _stream()), "rlgan_sigmoid_ce")
         dh3 = self.l2.backward(h3, logits, dlogits, act=False)
@@ -277,3 +279,59 @@ class PixelDiscriminator:
         self.step.add_(1)
         _adam_jobs(self._opt, self.step, self.lr if lr is None else lr)
         return self.losses
+
+
+class PixelGanTrainer:
+    """The GAN half of the pixel variant's training iteration on one minibatch (Curious_GAN_mario.py:85-93):
+
+        b_s, b_a, b_s_ = M.sample(BATCH_SIZE)
+        generator.learn(b_s, b_a, lr, b_s_);  b_g = generator.predict_batch(b_s, b_a)
+        discriminator.learn(b_g, b_s_[:, :, :, [-1]], b_s, b_a, lr)
+
+    with the frames in a uint8 `FrameMemory` (read in place by the state encoder), the actions in a float
+    `DeviceMemory` with the same slots, and the minibatch named by an index array on the device.  `capture()`
+    records the iteration as one HIP graph: at the reference's batch of 32 the ~100 launches cost more than
+    their kernels."""
+
+    def __init__(self, frames, actions, generator: PixelGenerator, discriminator: PixelDiscriminator, batch: int):
+        self.frames, self.actions, self.G, self.D, self.batch = frames, actions, generator, discriminator, int(batch)
+        self.idx = torch.zeros(self.batch, dtype=torch.int64, device=device())
+        self._graph = None
+
+    def sample(self) -> torch.Tensor:
+        """np.random.choice(len, n) of the reference's replay (Conv_model.py:147) into the step's index array."""
+        return self.frames.sample_indices(self.batch, out=self.idx)
+
+    def _body(self) -> None:
+        F, G, D = self.frames, self.G, self.D
+        ref = F.ref(self.idx, "s")
+        phis = D.state_encoder.forward(ref)
+        a = self.actions.gather(self.idx)
+        s_next = F.gather(self.idx, "s_")
+        n, h, w, c = s_next.shape
+        last = torch.empty((n, h, w, 1), dtype=torch.float32, device=s_next.device)
+        check(lib.rlgan_copy_cols(s_next.data_ptr() + 4 * (c - 1), c, last.data_ptr(), 1, n * h * w, 1, 0, _stream()), "rlgan_copy_cols")
+        G.learn(phis, a, last)
+        img = G.predict_batch(phis, a)
+        D.learn(img, last, ref, a, phis=phis)
+
+    def capture(self) -> None:
+        cur = torch.cuda.current_stream()
+        s = torch.cuda.Stream()
+        s.wait_stream(cur)
+        with torch.cuda.stream(s):
+            for _ in range(2):                                   # every buffer and kernel attribute exists before recording
+                self._body()
+        cur.wait_stream(s)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._body()
+        self._graph = g
+
+    def step(self) -> None:
+        """One iteration on the indices currently in `idx`; losses in `G.loss_out` and `D.losses`."""
+        if self._graph is not None:
+            self._graph.replay()
+        else:
+            self._body()
