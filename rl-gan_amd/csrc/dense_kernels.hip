@@ -66,6 +66,18 @@ __device__ __forceinline__ void tile_load(f32x4 (&r)[2], const float* __restrict
     r[h] = v;
   }
 }
+// The same for a tile that lies wholly inside the operand and holds no ones index: no per-lane condition.
+// (Conditions around the loads make the wave wait for them where the branches join, i.e. before the
+// multiplications they are meant to overlap with; the main loop below therefore runs on this form alone.)
+template <bool KCONT>
+__device__ __forceinline__ void tile_load_inside(f32x4 (&r)[2], const float* __restrict__ p, int ld, int x0, int k0) {
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int u = threadIdx.x + 256 * h;
+    r[h] = KCONT ? *(const f32x4*)(p + (size_t)(x0 + (u >> 3)) * ld + k0 + (u & 7) * 4)
+                 : *(const f32x4*)(p + (size_t)(k0 + (u >> 4)) * ld + x0 + (u & 15) * 4);
+  }
+}
 // the registers of tile_load into an LDS tile [64 x][LDT], k contiguous
 template <bool KCONT>
 __device__ __forceinline__ void tile_store(float* t, const f32x4 (&r)[2]) {
@@ -104,18 +116,25 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
   const int kb = (int)blockIdx.y * g.k_split;                       // this split's reduction range
   const int nkt = cdiv(min(g.K - kb, g.k_split), BK);
   float* cz = g.c + (size_t)blockIdx.y * g.slab;
-  tile_load<A_KCONT>(ra, g.a, g.lda, m0, kb, ax, ak, g.ones_x, g.ones_k);
-  tile_load<B_KCONT>(rb, g.b, g.ldb, n0, kb, g.b_x, g.b_k, -1, -1);
-  tile_store<A_KCONT>(lds, ra);
-  tile_store<B_KCONT>(lds + TILE_FLOATS, rb);
-  __syncthreads();
-  for (int kt = 0; kt < nkt; ++kt) {
+  // leading reduction steps whose A and B tiles lie wholly inside the operands (no edge, no ones index)
+  int nin = 0;
+  if (m0 + BM <= ax && n0 + BN <= g.b_x && (g.ones_x < m0 || g.ones_x >= m0 + BM)) {
+    int kin = min(ak, g.b_k);
+    if (g.ones_k >= 0) kin = min(kin, g.ones_k);
+    nin = max(0, min(nkt, (kin - kb) / BK));
+  }
+  auto load = [&](int kt, bool inside) {
+    if (inside) {
+      tile_load_inside<A_KCONT>(ra, g.a, g.lda, m0, kb + kt * BK);
+      tile_load_inside<B_KCONT>(rb, g.b, g.ldb, n0, kb + kt * BK);
+    } else {
+      tile_load<A_KCONT>(ra, g.a, g.lda, m0, kb + kt * BK, ax, ak, g.ones_x, g.ones_k);
+      tile_load<B_KCONT>(rb, g.b, g.ldb, n0, kb + kt * BK, g.b_x, g.b_k, -1, -1);
+    }
+  };
+  auto multiply = [&](int kt) {
     const float* as = lds + (kt & 1) * 2 * TILE_FLOATS;
     const float* bs = as + TILE_FLOATS;
-    if (kt + 1 < nkt) {
-      tile_load<A_KCONT>(ra, g.a, g.lda, m0, kb + (kt + 1) * BK, ax, ak, g.ones_x, g.ones_k);
-      tile_load<B_KCONT>(rb, g.b, g.ldb, n0, kb + (kt + 1) * BK, g.b_x, g.b_k, -1, -1);
-    }
 #pragma unroll
     for (int kg = 0; kg < BK / 16; ++kg) {
       f32x4 a[2], b[2];
@@ -133,11 +152,28 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
         }
       }
     }
-    if (kt + 1 < nkt) {
-      float* an = lds + ((kt + 1) & 1) * 2 * TILE_FLOATS;
-      tile_store<A_KCONT>(an, ra);
-      tile_store<B_KCONT>(an + TILE_FLOATS, rb);
-    }
+  };
+  auto stash = [&](int kt) {
+    float* an = lds + (kt & 1) * 2 * TILE_FLOATS;
+    tile_store<A_KCONT>(an, ra);
+    tile_store<B_KCONT>(an + TILE_FLOATS, rb);
+  };
+  load(0, nin > 0);
+  stash(0);
+  __syncthreads();
+  int kt = 0;
+  for (; kt + 1 < nin; ++kt) {          // the bulk: the next step's tiles are inside, nothing but loads, products, stores
+    load(kt + 1, true);
+    __builtin_amdgcn_sched_barrier(0);  // keep the fetches ahead of the products (the scheduler would sink them to their use)
+    multiply(kt);
+    __builtin_amdgcn_sched_barrier(0);
+    stash(kt + 1);
+    __syncthreads();
+  }
+  for (; kt < nkt; ++kt) {              // the edge steps (and everything, for a tile on the operands' border)
+    if (kt + 1 < nkt) load(kt + 1, false);
+    multiply(kt);
+    if (kt + 1 < nkt) stash(kt + 1);
     __syncthreads();
   }
   // lane (q, j) of an accumulator tile holds rows 4q..4q+3 of column j
