@@ -26,6 +26,38 @@ __device__ __forceinline__ float mat_at(const Mat& m, int gr, int c) {
 constexpr int STAGE_LD = 32, STAGE_FLOATS = ROWS * STAGE_LD;
 __device__ __forceinline__ void stage_rows(float* stage, int row0, int n_rows, MatIn b0, MatIn b1, MatIn b2, MatIn b3) {
   const int e0 = b0.w, e1 = e0 + b1.w, e2 = e1 + b2.w, e3 = e2 + b3.w;
+  const bool all_idx = b0.idx && (!b1.w || b1.idx) && (!b2.w || b2.idx) && (!b3.w || b3.idx);
+  const bool no_idx = !b0.idx && !b1.idx && !b2.idx && !b3.idx;
+  const bool global = !b0.local && !b1.local && !b2.local && !b3.local;
+  if (global && (all_idx || no_idx)) {
+    // The usual case, without a branch around any load: which block a lane reads is a matter of selects, so the
+    // index loads of all its elements go out together, then the row loads -- two memory round trips in all.
+    // (One branch per block made it eight, each waited for where the branches join.)
+    constexpr int PER = STAGE_FLOATS / THREADS;
+    long long row[PER];
+    const float* src[PER];
+    bool ok[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int e = threadIdx.x + i * THREADS, r = e / STAGE_LD, c = e % STAGE_LD, gr = row0 + r;
+      ok[i] = gr < n_rows && c < e3;
+      const int which = ok[i] ? (c >= e0) + (c >= e1) + (c >= e2) : 0;
+      const float* p = which == 0 ? b0.p : which == 1 ? b1.p : which == 2 ? b2.p : b3.p;
+      const long long* ix = which == 0 ? b0.idx : which == 1 ? b1.idx : which == 2 ? b2.idx : b3.idx;
+      const int ld = which == 0 ? b0.ld : which == 1 ? b1.ld : which == 2 ? b2.ld : b3.ld;
+      const int cc = ok[i] ? c - (which == 0 ? 0 : which == 1 ? e0 : which == 2 ? e1 : e2) : 0;
+      const int g0 = ok[i] ? gr : 0;                          // row 0 exists
+      row[i] = all_idx ? ix[g0] : (long long)g0;
+      src[i] = p + cc;
+      row[i] *= ld;
+    }
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const float v = src[i][row[i]];
+      stage[threadIdx.x + i * THREADS] = ok[i] ? v : 0.f;
+    }
+    return;
+  }
   for (int e = threadIdx.x; e < STAGE_FLOATS; e += THREADS) {
     const int r = e / STAGE_LD, c = e % STAGE_LD;
     const int gr = row0 + r;
