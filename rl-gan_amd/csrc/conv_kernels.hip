@@ -394,15 +394,24 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const ConvG g, const S 
         if (q < KP / 4) *(f32x4*)(P + pl * ldp + 4 * q) = in ? patch_value(src, raw[i], ps.base, kf[i]) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
     }
-    for (int e = threadIdx.x; e < WG_PIX * NT * 16; e += 256) {
-      const int pl = e / (NT * 16), n = e - pl * (NT * 16);
-      const int p = p0 + pl;
-      float v = 0.f;
-      if (p < p_end && n < g.Cout) {
-        v = dz[(size_t)p * g.Cout + n];
-        if (yelu) v *= elu_d(yelu[(size_t)p * g.Cout + n]);      // dz is dY: times ELU'(y) on the way in
+    {
+      // no branch around the loads (a wave would wait for each where the branches join): element 0 stands in
+      constexpr int ZPER = WG_PIX * NT * 16 / 256;
+      float zv[ZPER], yv[ZPER];
+      bool zok[ZPER];
+#pragma unroll
+      for (int i = 0; i < ZPER; ++i) {
+        const int e = threadIdx.x + 256 * i, pl = e / (NT * 16), n = e - pl * (NT * 16), p = p0 + pl;
+        zok[i] = p < p_end && n < g.Cout;
+        const size_t at = zok[i] ? (size_t)p * g.Cout + n : 0;
+        zv[i] = dz[at];
+        yv[i] = yelu ? yelu[at] : 1.f;                           // dz is dY: times ELU'(y) on the way in
       }
-      Z[pl * ldz + n] = v;
+#pragma unroll
+      for (int i = 0; i < ZPER; ++i) {
+        const int e = threadIdx.x + 256 * i, pl = e / (NT * 16), n = e - pl * (NT * 16);
+        Z[pl * ldz + n] = zok[i] ? zv[i] * elu_d(yv[i]) : 0.f;
+      }
     }
     __syncthreads();
     // A[row = patch element][kk = pixel], B[kk = pixel][col = channel]
