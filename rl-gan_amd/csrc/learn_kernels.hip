@@ -568,6 +568,12 @@ __global__ __launch_bounds__(256) void apply_kernel(const ApplyArgs A) {
     if (threadIdx.x == 0) J.loss_out[0] = s * J.loss_scale;
   }
   if (p >= J.n) return;
+  // everything the update reads goes out first, so that these round trips overlap with the chunk sum and the
+  // step-size arithmetic instead of following them (job fields are the same for the whole workgroup: scalar branches)
+  const float w_old = J.canon[p], s0_old = J.slot0[p];
+  const float s1_old = J.opt == 1 ? J.slot1[p] : 0.f;
+  const int t_adam = J.opt == 1 ? J.step[0] : 1;
+  __builtin_amdgcn_sched_barrier(0);
   float g;
   if (J.gslabs) {
     const float* src = J.gslabs + J.map_g[p];
@@ -585,18 +591,18 @@ __global__ __launch_bounds__(256) void apply_kernel(const ApplyArgs A) {
   if (J.opt == 0) {
     // tf.train.RMSPropOptimizer: ms <- decay*ms + (1-decay)*g^2 ; w <- w - lr*g/sqrt(ms + eps)
     const float decay = (float)J.beta1;
-    const float m = decay * J.slot0[p] + (1.f - decay) * g * g;
+    const float m = decay * s0_old + (1.f - decay) * g * g;
     J.slot0[p] = m;
-    w = J.canon[p] - (float)J.lr * g / sqrtf(m + J.eps);
+    w = w_old - (float)J.lr * g / sqrtf(m + J.eps);
   } else {
     // tf.train.AdamOptimizer: lr_t = lr*sqrt(1-b2^t)/(1-b1^t); w <- w - lr_t*m/(sqrt(v)+eps)
-    const int t = J.step[0];
+    const int t = t_adam;
     const float lr_t = (float)(J.lr * sqrt(1.0 - pow(J.beta2, (double)t)) / (1.0 - pow(J.beta1, (double)t)));
     const float fb1 = (float)J.beta1, fb2 = (float)J.beta2;
-    const float m = fb1 * J.slot0[p] + (1.f - fb1) * g;
-    const float v = fb2 * J.slot1[p] + (1.f - fb2) * g * g;
+    const float m = fb1 * s0_old + (1.f - fb1) * g;
+    const float v = fb2 * s1_old + (1.f - fb2) * g * g;
     J.slot0[p] = m; J.slot1[p] = v;
-    w = J.canon[p] - lr_t * m / (sqrtf(v) + J.eps);
+    w = w_old - lr_t * m / (sqrtf(v) + J.eps);
   }
   J.canon[p] = w;
   const int of = J.wf ? J.map_f[p] : -1;                   // -1: this parameter has no place in the image (or there is no image)
