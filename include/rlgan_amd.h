@@ -471,6 +471,26 @@ int rlgan_sigmoid_ce(const float* logits, int ld, int n_real, int n_fake, float*
 /* out[r] = 1 - sigmoid(logits[r][0]), r < n: the intrinsic reward `1 - D_fake` (Conv_model.py:294,298) */
 int rlgan_one_minus_sigmoid(const float* logits, int ld, int n, float* out, void* stream);
 
+/* ---- inverse model of the pixel variant (StateActionPredictor, Conv_model.py:787-881) ------------------
+ * tf.layers.batch_normalization over the feature axis (Conv_model.py:838,844,850; defaults: epsilon 1e-3, trained
+ * gamma and beta) fused with the relu6 that follows it (act 3; 0: none):
+ *   training != 0: y = act(gamma * (z - mean) / sqrt(var + eps) + beta) with the mean and biased variance of
+ *                  the m rows, which are written to save_mean / save_inv_std (1 / sqrt(var + eps)) for the backward;
+ *   training == 0: the moving statistics, which the reference leaves at their initial 0 and 1 (its update ops are
+ *                  never run): y = act(gamma * z / sqrt(1 + eps) + beta); save_* may be NULL. */
+int rlgan_batchnorm_forward(const float* z, int ldz, const float* gamma, const float* beta, int m, int n, float eps, int training,
+                            int act, float* y, int ldy, float* save_mean, float* save_inv_std, void* stream);
+/* Gradient of the training-mode form: dy is the gradient of the activated output y (needed when act == 3);
+ * writes dz [m][n], dgamma[n], dbeta[n].  Column sums in a fixed order. */
+int rlgan_batchnorm_backward(const float* dy, int lddy, const float* y, int ldy, const float* z, int ldz, const float* gamma,
+                             const float* save_mean, const float* save_inv_std, int m, int n, int act, float* dz, int lddz,
+                             float* dgamma, float* dbeta, void* stream);
+/* tf.nn.sparse_softmax_cross_entropy_with_logits(logits, tf.argmax(a, 1)) per row (Conv_model.py:801,818):
+ * loss_rows[r] (the loss is their mean: rlgan_sum_parts(loss_rows, m, 1, 1/m)); when dlogits is non-NULL,
+ * dlogits[r][c] = (softmax - onehot) / m for c < n_classes and 0 for the padding columns up to ld. */
+int rlgan_softmax_ce(const float* logits, int ld, int n_classes, const float* a, int ld_a, int m, float* loss_rows, float* dlogits,
+                     void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,149 @@
+// Batch normalisation and the softmax cross-entropy of the pixel variant's inverse model
+// (`StateActionPredictor`, Conv_model.py:787-881): tf.layers.batch_normalization over the feature axis with its
+// defaults (epsilon 1e-3, gamma/beta trained) after every dense layer, relu6 after the first two, and
+// tf.nn.sparse_softmax_cross_entropy_with_logits against argmax(a).  The reference never runs the moving-average
+// update ops (no control dependency on UPDATE_OPS anywhere), so inference normalises with the initial moving
+// statistics (mean 0, variance 1): `training == 0` below.  All column sums run in a fixed order.  gfx950 only.
+#include "rlgan_device.h"
+#include "rlgan_host.h"
+
+using namespace rlgan;
+
+namespace {
+
+constexpr int BN_COLS = 64, BN_PH = 4;      // a workgroup owns 64 columns; four row phases per column
+
+__device__ __forceinline__ float relu6_d(float y) { return y > 0.f && y < 6.f ? 1.f : 0.f; }
+
+// sum over the four row phases of a column, in phase order; every thread of the column gets it
+__device__ __forceinline__ float phase_sum(float* sh, float v) {
+  const int c = threadIdx.x & (BN_COLS - 1), ph = threadIdx.x / BN_COLS;
+  __syncthreads();
+  sh[ph * BN_COLS + c] = v;
+  __syncthreads();
+  return ((sh[c] + sh[BN_COLS + c]) + sh[2 * BN_COLS + c]) + sh[3 * BN_COLS + c];
+}
+
+// y = act(gamma * (z - mean) * inv_std + beta) per column; training: mean / biased variance of the m rows
+__global__ __launch_bounds__(256) void bn_forward_kernel(const float* __restrict__ z, int ldz, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, int m, int n, float eps, int training, int act,
+                                                         float* __restrict__ y, int ldy, float* __restrict__ save_mean,
+                                                         float* __restrict__ save_inv_std) {
+  __shared__ float sh[256];
+  const int c = blockIdx.x * BN_COLS + (threadIdx.x & (BN_COLS - 1)), ph = threadIdx.x / BN_COLS;
+  const bool in = c < n;
+  float mean = 0.f, inv_std = rsqrtf(1.f + eps);
+  if (training) {
+    float s = 0.f;
+    if (in) for (int r = ph; r < m; r += BN_PH) s += z[(size_t)r * ldz + c];
+    mean = phase_sum(sh, s) / (float)m;
+    float q = 0.f;
+    if (in) for (int r = ph; r < m; r += BN_PH) { const float d = z[(size_t)r * ldz + c] - mean; q += d * d; }
+    inv_std = 1.f / sqrtf(phase_sum(sh, q) / (float)m + eps);
+  } else {
+    inv_std = 1.f / sqrtf(1.f + eps);
+  }
+  if (!in) return;
+  if (ph == 0 && save_mean) { save_mean[c] = mean; save_inv_std[c] = inv_std; }
+  const float ga = gamma[c], be = beta[c];
+  for (int r = ph; r < m; r += BN_PH) {
+    float v = ga * ((z[(size_t)r * ldz + c] - mean) * inv_std) + be;
+    if (act == 3) v = __builtin_amdgcn_fmed3f(v, 0.f, 6.f);
+    y[(size_t)r * ldy + c] = v;
+  }
+}
+
+// training-mode gradient: dyh = dy * relu6'(y) (act == 3); xh = (z - mean) * inv_std;
+// dgamma = sum dyh * xh, dbeta = sum dyh, dz = gamma * inv_std * (dyh - dbeta / m - xh * dgamma / m)
+__global__ __launch_bounds__(256) void bn_backward_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ y, int ldy,
+                                                          const float* __restrict__ z, int ldz, const float* __restrict__ gamma,
+                                                          const float* __restrict__ mean_, const float* __restrict__ inv_std_, int m, int n,
+                                                          int act, float* __restrict__ dz, int lddz, float* __restrict__ dgamma,
+                                                          float* __restrict__ dbeta) {
+  __shared__ float sh[256];
+  const int c = blockIdx.x * BN_COLS + (threadIdx.x & (BN_COLS - 1)), ph = threadIdx.x / BN_COLS;
+  const bool in = c < n;
+  const float mean = in ? mean_[c] : 0.f, inv_std = in ? inv_std_[c] : 0.f, ga = in ? gamma[c] : 0.f;
+  float sg = 0.f, sb = 0.f;
+  if (in) {
+    for (int r = ph; r < m; r += BN_PH) {
+      float d = dy[(size_t)r * lddy + c];
+      if (act == 3) d *= relu6_d(y[(size_t)r * ldy + c]);
+      sg += d * ((z[(size_t)r * ldz + c] - mean) * inv_std);
+      sb += d;
+    }
+  }
+  const float dg = phase_sum(sh, sg), db = phase_sum(sh, sb);
+  if (!in) return;
+  if (ph == 0) { dgamma[c] = dg; dbeta[c] = db; }
+  const float k = ga * inv_std, im = 1.f / (float)m;
+  for (int r = ph; r < m; r += BN_PH) {
+    float d = dy[(size_t)r * lddy + c];
+    if (act == 3) d *= relu6_d(y[(size_t)r * ldy + c]);
+    const float xh = (z[(size_t)r * ldz + c] - mean) * inv_std;
+    dz[(size_t)r * lddz + c] = k * (d - db * im - xh * dg * im);
+  }
+}
+
+// one thread per row: label = first index of the row maximum of a (tf.argmax), loss_rows[r] = logsumexp - logit[label],
+// dlogits = (softmax - onehot) / m with the columns from n_classes to ld zeroed
+__global__ void softmax_ce_kernel(const float* __restrict__ logits, int ld, int n_classes, const float* __restrict__ a, int ld_a, int m,
+                                  float* __restrict__ loss_rows, float* __restrict__ dlogits) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= m) return;
+  const float* x = logits + (size_t)r * ld;
+  const float* ar = a + (size_t)r * ld_a;
+  int label = 0;
+  float amax = ar[0], xmax = x[0];
+  for (int c = 1; c < n_classes; ++c) {
+    if (ar[c] > amax) { amax = ar[c]; label = c; }
+    xmax = fmaxf(xmax, x[c]);
+  }
+  float se = 0.f;
+  for (int c = 0; c < n_classes; ++c) se += expf(x[c] - xmax);
+  loss_rows[r] = logf(se) + xmax - x[label];
+  if (dlogits) {
+    float* d = dlogits + (size_t)r * ld;
+    const float im = 1.f / (float)m;
+    for (int c = 0; c < ld; ++c) d[c] = c < n_classes ? (expf(x[c] - xmax) / se - (c == label ? 1.f : 0.f)) * im : 0.f;
+  }
+}
+
+inline int launched() { return (int)hipGetLastError(); }
+
+}  // namespace
+
+extern "C" {
+
+int rlgan_batchnorm_forward(const float* z, int ldz, const float* gamma, const float* beta, int m, int n, float eps, int training,
+                            int act, float* y, int ldy, float* save_mean, float* save_inv_std, void* stream) {
+  if (!z || !gamma || !beta || !y || m <= 0 || n <= 0 || (act != 0 && act != 3) || (training && (!save_mean || !save_inv_std)))
+    return RLGAN_E_ARG;
+  if (ldz < n || ldy < n) return RLGAN_E_ALIGN;
+  hipLaunchKernelGGL(bn_forward_kernel, dim3(cdiv(n, BN_COLS)), dim3(256), 0, (hipStream_t)stream, z, ldz, gamma, beta, m, n, eps,
+                     training, act, y, ldy, save_mean, save_inv_std);
+  return launched();
+}
+
+int rlgan_batchnorm_backward(const float* dy, int lddy, const float* y, int ldy, const float* z, int ldz, const float* gamma,
+                             const float* save_mean, const float* save_inv_std, int m, int n, int act, float* dz, int lddz,
+                             float* dgamma, float* dbeta, void* stream) {
+  if (!dy || !z || !gamma || !save_mean || !save_inv_std || !dz || !dgamma || !dbeta || m <= 0 || n <= 0 || (act != 0 && act != 3) ||
+      (act == 3 && !y))
+    return RLGAN_E_ARG;
+  if (lddy < n || ldz < n || lddz < n || (y && ldy < n)) return RLGAN_E_ALIGN;
+  hipLaunchKernelGGL(bn_backward_kernel, dim3(cdiv(n, BN_COLS)), dim3(256), 0, (hipStream_t)stream, dy, lddy, y, ldy, z, ldz, gamma,
+                     save_mean, save_inv_std, m, n, act, dz, lddz, dgamma, dbeta);
+  return launched();
+}
+
+int rlgan_softmax_ce(const float* logits, int ld, int n_classes, const float* a, int ld_a, int m, float* loss_rows, float* dlogits,
+                     void* stream) {
+  if (!logits || !a || !loss_rows || m <= 0 || n_classes <= 0) return RLGAN_E_ARG;
+  if (ld < n_classes || ld_a < n_classes) return RLGAN_E_ALIGN;
+  hipLaunchKernelGGL(softmax_ce_kernel, dim3(cdiv(m, 256)), dim3(256), 0, (hipStream_t)stream, logits, ld, n_classes, a, ld_a, m,
+                     loss_rows, dlogits);
+  return launched();
+}
+
+}  // extern "C"
