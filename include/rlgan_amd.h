@@ -218,7 +218,7 @@ int rlgan_grad_reduce(const rlgan_reduce_job_t* jobs, int n_jobs, void* stream);
  *         rlgan_grad_reduce), eps outside the sqrt.
  * When target_canon is non-NULL the job also updates that target network from the new weights:
  * target <- tau*w + (1-tau)*target when (counter[0]-1) % period == 0 (counter NULL: always); the
- * reference only has the hard copy, tau = 1 (DDPG.py:99-101,176-178).
+ * reference only has the hard copy, tau = 1 (DDPG.py:99-101,176-178); target_wf may be NULL when wf is.
  * When `reduce` is non-NULL the reduction it describes (see rlgan_grad_reduce; its `counter` must be
  * NULL, its n_params equal) runs in the same launch and feeds the optimizer directly, `grad` is then
  * ignored and reduce->grad, if non-NULL, receives the gradient: the one-process form, where nothing
@@ -406,7 +406,7 @@ int rlgan_conv_backward_weights(const rlgan_conv_t* conv, const float* x, const 
  * wb: canonical parameters on the device, the [k, n] kernel (row-major, TF layout) followed by the
  * bias row [n].  x: [m, k] with leading dimension ldx; y, dz: [m, n].  Bases 16-byte aligned, leading
  * dimensions multiples of four.
- *   forward:          y = act(x * W + b), act: 0 linear, 1 ELU
+ *   forward:          y = act(x * W + b), act: 0 linear, 1 ELU, 2 ReLU, 3 relu6, 4 tanh
  *   backward_input:   dx[m, k] = dz * W^T           (dz already times ELU'(y): rlgan_elu_backward)
  *   backward_weights: gwb[k+1, n] = [x 1]^T * dz    (kernel gradient, then the bias gradient row)
  * The sum over the long dimension can be cut into n_slabs ranges (more workgroups when the output alone
@@ -490,6 +490,16 @@ int rlgan_batchnorm_backward(const float* dy, int lddy, const float* y, int ldy,
  * dlogits[r][c] = (softmax - onehot) / m for c < n_classes and 0 for the padding columns up to ld. */
 int rlgan_softmax_ce(const float* logits, int ld, int n_classes, const float* a, int ld_a, int m, float* loss_rows, float* dlogits,
                      void* stream);
+
+/* dz = dy * act'(y) from the activated output y: act 3 = relu6 (mask 0 < y < 6), act 4 = tanh (1 - y^2); the
+ * activations of the pixel variant's actor and critic (Conv_model.py:634,641,648,721,728,735,742). */
+int rlgan_act_backward(const float* dy, const float* y, float* dz, int64_t n, int act, void* stream);
+
+/* TD error of the pixel critic (Conv_model.py:609-613): d[r] = q[r][0] - (reward[r] + gamma * q_next[r][0]), r < m;
+ * parts[b] = sum of d^2 over rows 256 b .. 256 b + 255 (the loss is rlgan_sum_parts(parts, ceil(m / 256), 1, 1 / m));
+ * when dq is non-NULL, dq[r][0] = 2 d[r] / m and dq[r][1 .. ld) = 0.  q, q_next, dq: leading dimension ld. */
+int rlgan_td_error(const float* q, const float* q_next, int ld, const float* reward, float gamma, int m, float* parts, float* dq,
+                   void* stream);
 
 #ifdef __cplusplus
 }

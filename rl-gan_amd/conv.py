@@ -177,8 +177,9 @@ class DenseLayer:
 
     @staticmethod
     def _act_code(act) -> int:
-        """True / "elu": ELU (the encoders' head); "relu": ReLU (the pixel generator's first layer); False / None: linear."""
-        return {True: 1, "elu": 1, "relu": 2, False: 0, None: 0}[act]
+        """True / "elu": ELU (the encoders' head); "relu": ReLU (the pixel generator's first layer); "relu6" and "tanh":
+        the pixel actor and critic; False / None: linear."""
+        return {True: 1, "elu": 1, "relu": 2, "relu6": 3, "tanh": 4, False: 0, None: 0}[act]
 
     def forward(self, x: torch.Tensor, act=True) -> torch.Tensor:
         assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.ndim == 2 and x.shape[1] == self.k
@@ -195,8 +196,11 @@ class DenseLayer:
         code = self._act_code(act)
         if code:
             dz = torch.empty_like(dy)
-            fn, name = (lib.rlgan_elu_backward, "rlgan_elu_backward") if code == 1 else (lib.rlgan_relu_backward, "rlgan_relu_backward")
-            check(fn(dy.data_ptr(), y.data_ptr(), dz.data_ptr(), dy.numel(), _stream()), name)
+            if code >= 3:
+                check(lib.rlgan_act_backward(dy.data_ptr(), y.data_ptr(), dz.data_ptr(), dy.numel(), code, _stream()), "rlgan_act_backward")
+            else:
+                fn, name = (lib.rlgan_elu_backward, "rlgan_elu_backward") if code == 1 else (lib.rlgan_relu_backward, "rlgan_relu_backward")
+                check(fn(dy.data_ptr(), y.data_ptr(), dz.data_ptr(), dy.numel(), _stream()), name)
         sc, ns = self._slabs(self.k + 1, m)
         check(lib.rlgan_dense_backward_weights(x.data_ptr(), self.k, dz.data_ptr(), self.n, self.grad.data_ptr(), m, self.k, self.n,
                                                None if sc is None else sc.data_ptr(), ns, _stream()), "rlgan_dense_backward_weights")

@@ -27,7 +27,7 @@ struct GemmArgs {
   int a_x, a_k;         // extents of A in memory along its non-reduction / reduction dimension
   int b_x, b_k;         // the same for B
   int ones_x, ones_k;   // A reads as 1 at this non-reduction (reduction) index; -1: none
-  int act;              // epilogue: 1 = ELU, 2 = ReLU
+  int act;              // epilogue: 1 = ELU, 2 = ReLU, 3 = relu6, 4 = tanh
   int k_split;          // reduction indices per blockIdx.y (a multiple of BK); with more than one split the
   size_t slab;          // raw partial products go to c + blockIdx.y * slab and split_sum_kernel finishes
 };
@@ -189,6 +189,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
           float v = acc[s][t][r];
           if (g.act == 1) v = v > 0.f ? v : expm1f(v);
           else if (g.act == 2) v = fmaxf(v, 0.f);
+          else if (g.act == 3) v = __builtin_amdgcn_fmed3f(v, 0.f, 6.f);
+          else if (g.act == 4) v = tanhf(v);
           cz[(size_t)row * g.ldc + col] = v;
         }
       }
@@ -205,6 +207,8 @@ __global__ __launch_bounds__(256) void split_sum_kernel(const float* __restrict_
   for (int z = 0; z < n_slabs; ++z) v += slabs[z * slab + i];
   if (act == 1) v = v > 0.f ? v : expm1f(v);
   else if (act == 2) v = fmaxf(v, 0.f);
+  else if (act == 3) v = __builtin_amdgcn_fmed3f(v, 0.f, 6.f);
+  else if (act == 4) v = tanhf(v);
   c[(i / N) * ldc + i % N] = v;
 }
 
@@ -254,7 +258,7 @@ int rlgan_dense_slabs(int m_out, int n_out, int k_red) {
 
 int rlgan_dense_forward(const float* x, int ldx, const float* wb, float* y, int ldy, int m, int k, int n, int act,
                         float* slabs, int n_slabs, void* stream) {
-  if (ldx < k || ldy < n || act < 0 || act > 2) return RLGAN_E_ARG;
+  if (ldx < k || ldy < n || act < 0 || act > 4) return RLGAN_E_ARG;
   GemmArgs g{x, wb, y, ldx, n, ldy, m, n, k + 1, /*a_x*/ m, /*a_k*/ k, /*b_x*/ n, /*b_k*/ k + 1, /*ones_x*/ -1, /*ones_k*/ k, act, 0, 0};
   return launch_gemm<true, false>(g, slabs, n_slabs, stream);
 }

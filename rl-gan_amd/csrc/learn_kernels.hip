@@ -837,10 +837,9 @@ int rlgan_apply(const rlgan_apply_job_t* jobs, int n_jobs, void* stream) {
   for (int i = 0; i < n_jobs; ++i) {
     const rlgan_apply_job_t& J = jobs[i];
     if (!J.canon || (!J.grad && !J.reduce) || !J.slot0 || (J.wf && !J.map_f) || J.n_params <= 0 || (J.wb && !J.map_b)) return RLGAN_E_ARG;
-    if (!J.wf && J.target_canon) return RLGAN_E_ARG;
     if (J.opt != 0 && J.opt != 1) return RLGAN_E_ARG;
     if (J.opt == 1 && (!J.slot1 || !J.step)) return RLGAN_E_ARG;
-    if (J.target_canon && (!J.target_wf || (J.counter && J.period <= 0))) return RLGAN_E_ARG;
+    if (J.target_canon && ((J.wf && !J.target_wf) || (J.counter && J.period <= 0))) return RLGAN_E_ARG;
     ApplyJob& K = A.job[i];
     K.canon = J.canon; K.grad = J.grad; K.slot0 = J.slot0; K.slot1 = J.slot1;
     K.map_f = J.map_f; K.wf = J.wf; K.map_b = J.map_b; K.wb = J.wb; K.step = J.step;

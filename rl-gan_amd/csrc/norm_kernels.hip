@@ -109,6 +109,37 @@ __global__ void softmax_ce_kernel(const float* __restrict__ logits, int ld, int 
   }
 }
 
+// dz = dy * act'(y) from the activated output y: relu6 (3): 0 < y < 6; tanh (4): 1 - y^2
+__global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dz, size_t n, int act) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float v = y[i];
+  dz[i] = dy[i] * (act == 3 ? relu6_d(v) : 1.f - v * v);
+}
+
+// TD error of the pixel critic: d = q[r][0] - (reward[r] + gamma * q_next[r][0]); parts[block] = sum of d^2 over the block's
+// rows (wave sums by shuffles, then the four waves in order); dq[r] = (2 d / m, 0, 0, ...) over the ld columns
+__global__ __launch_bounds__(256) void td_error_kernel(const float* __restrict__ q, const float* __restrict__ q_next, int ld,
+                                                       const float* __restrict__ reward, float gamma, int m, float* __restrict__ parts,
+                                                       float* __restrict__ dq) {
+  __shared__ float sh[4];
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  float d = 0.f;
+  if (r < m) {
+    d = q[(size_t)r * ld] - (reward[r] + gamma * q_next[(size_t)r * ld]);
+    if (dq) {
+      dq[(size_t)r * ld] = 2.f * d / (float)m;
+      for (int c = 1; c < ld; ++c) dq[(size_t)r * ld + c] = 0.f;
+    }
+  }
+  float s = d * d;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) parts[blockIdx.x] = ((sh[0] + sh[1]) + sh[2]) + sh[3];
+}
+
 inline int launched() { return (int)hipGetLastError(); }
 
 }  // namespace
@@ -143,6 +174,19 @@ int rlgan_softmax_ce(const float* logits, int ld, int n_classes, const float* a,
   if (ld < n_classes || ld_a < n_classes) return RLGAN_E_ALIGN;
   hipLaunchKernelGGL(softmax_ce_kernel, dim3(cdiv(m, 256)), dim3(256), 0, (hipStream_t)stream, logits, ld, n_classes, a, ld_a, m,
                      loss_rows, dlogits);
+  return launched();
+}
+
+int rlgan_act_backward(const float* dy, const float* y, float* dz, int64_t n, int act, void* stream) {
+  if (!dy || !y || !dz || n <= 0 || (act != 3 && act != 4)) return RLGAN_E_ARG;
+  hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dy, y, dz, (size_t)n, act);
+  return launched();
+}
+
+int rlgan_td_error(const float* q, const float* q_next, int ld, const float* reward, float gamma, int m, float* parts, float* dq,
+                   void* stream) {
+  if (!q || !q_next || !reward || !parts || m <= 0 || ld <= 0) return RLGAN_E_ARG;
+  hipLaunchKernelGGL(td_error_kernel, dim3(cdiv(m, 256)), dim3(256), 0, (hipStream_t)stream, q, q_next, ld, reward, gamma, m, parts, dq);
   return launched();
 }
 
