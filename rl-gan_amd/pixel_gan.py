@@ -293,8 +293,17 @@ class PixelGanTrainer:
     records the iteration as one HIP graph: at the reference's batch of 32 the ~100 launches cost more than
     their kernels."""
 
-    def __init__(self, frames, actions, generator: PixelGenerator, discriminator: PixelDiscriminator, batch: int):
+    def __init__(self, frames, actions, generator: PixelGenerator, discriminator: PixelDiscriminator, batch: int,
+                 a_pred=None, actor=None, critic=None):
+        """With a_pred / critic / actor the iteration goes on as the reference's does (Curious_GAN_mario.py:96-98):
+
+            A_pred.learn(b_s, b_s_, b_a);  critic.learn(b_s, b_a, b_curious_r, b_s_);  actor.learn(b_s)
+
+        The rows of `actions` are then [a (a_dim), r, curious_r]; the critic's reward is the last column."""
         self.frames, self.actions, self.G, self.D, self.batch = frames, actions, generator, discriminator, int(batch)
+        self.a_pred, self.actor, self.critic = a_pred, actor, critic
+        assert (actor is None) == (critic is None)
+        assert critic is None or actions.dims >= discriminator.a_dim + 2
         self.idx = torch.zeros(self.batch, dtype=torch.int64, device=device())
         self._graph = None
 
@@ -306,7 +315,8 @@ class PixelGanTrainer:
         F, G, D = self.frames, self.G, self.D
         ref = F.ref(self.idx, "s")
         phis = D.state_encoder.forward(ref)
-        a = self.actions.gather(self.idx)
+        rows = self.actions.gather(self.idx)
+        a = rows[:, :self.D.a_dim].contiguous()
         s_next = F.gather(self.idx, "s_")
         n, h, w, c = s_next.shape
         last = torch.empty((n, h, w, 1), dtype=torch.float32, device=s_next.device)
@@ -314,6 +324,17 @@ class PixelGanTrainer:
         G.learn(phis, a, last)
         img = G.predict_batch(phis, a)
         D.learn(img, last, ref, a, phis=phis)
+        if self.a_pred is None and self.critic is None:
+            return
+        s = F.gather(self.idx, "s")
+        if self.a_pred is not None:
+            self.a_pred.learn(s, s_next, a)
+        if self.critic is not None:
+            r = rows[:, self.D.a_dim + 1:self.D.a_dim + 2].contiguous()
+            phis_next = self.critic.state_encoder.forward(s_next)
+            phis = self.critic.state_encoder.forward(s)
+            self.critic.learn(None, a, r, None, phis=phis, phis_next=phis_next)
+            self.actor.learn(None, self.critic, phis=phis)
 
     def capture(self) -> None:
         cur = torch.cuda.current_stream()
