@@ -479,12 +479,17 @@ int rlgan_one_minus_sigmoid(const float* logits, int ld, int n, float* out, void
  *   training == 0: the moving statistics, which the reference leaves at their initial 0 and 1 (its update ops are
  *                  never run): y = act(gamma * z / sqrt(1 + eps) + beta); save_* may be NULL. */
 int rlgan_batchnorm_forward(const float* z, int ldz, const float* gamma, const float* beta, int m, int n, float eps, int training,
-                            int act, float* y, int ldy, float* save_mean, float* save_inv_std, void* stream);
+                            int act, float* y, int ldy, float* save_mean, float* save_inv_std, float* scratch, void* stream);
 /* Gradient of the training-mode form: dy is the gradient of the activated output y (needed when act == 3);
  * writes dz [m][n], dgamma[n], dbeta[n].  Column sums in a fixed order. */
 int rlgan_batchnorm_backward(const float* dy, int lddy, const float* y, int ldy, const float* z, int ldz, const float* gamma,
                              const float* save_mean, const float* save_inv_std, int m, int n, int act, float* dz, int lddz,
-                             float* dgamma, float* dbeta, void* stream);
+                             float* dgamma, float* dbeta, float* scratch, void* stream);
+/* Row chunks the two calls above cut m rows into.  1 (m <= 256): one launch each, scratch unused (may be NULL).  Otherwise
+ * each call takes per-chunk partial results through `scratch`, device memory of 2 * chunks * n floats, joined in chunk
+ * order (chunk means and squared deviations by the pairwise update formula), and save_mean / save_inv_std are required
+ * in both modes. */
+int rlgan_batchnorm_chunks(int m);
 /* tf.nn.sparse_softmax_cross_entropy_with_logits(logits, tf.argmax(a, 1)) per row (Conv_model.py:801,818):
  * loss_rows[r] (the loss is their mean: rlgan_sum_parts(loss_rows, m, 1, 1/m)); when dlogits is non-NULL,
  * dlogits[r][c] = (softmax - onehot) / m for c < n_classes and 0 for the padding columns up to ld. */

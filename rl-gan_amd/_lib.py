@@ -184,8 +184,9 @@ PROTOTYPES = {
     "rlgan_add_cols": [_vp, _i, _vp, _i, C.c_int64, _i, _vp],
     "rlgan_sigmoid_ce": [_vp, _i, _i, _i, _vp, _vp, _vp],
     "rlgan_one_minus_sigmoid": [_vp, _i, _i, _vp, _vp],
-    "rlgan_batchnorm_forward": [_vp, _i, _vp, _vp, _i, _i, _f, _i, _i, _vp, _i, _vp, _vp, _vp],
-    "rlgan_batchnorm_backward": [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp],
+    "rlgan_batchnorm_forward": [_vp, _i, _vp, _vp, _i, _i, _f, _i, _i, _vp, _i, _vp, _vp, _vp, _vp],
+    "rlgan_batchnorm_chunks": [_i],
+    "rlgan_batchnorm_backward": [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp],
     "rlgan_act_backward": [_vp, _vp, _vp, C.c_int64, _i, _vp],
     "rlgan_td_error": [_vp, _vp, _i, _vp, _f, _i, _vp, _vp, _vp],
     "rlgan_softmax_ce": [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp],

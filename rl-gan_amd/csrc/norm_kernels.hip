@@ -85,6 +85,116 @@ __global__ __launch_bounds__(256) void bn_backward_kernel(const float* __restric
   }
 }
 
+// ---- the same two passes for many rows: the rows are cut into chunks, a (column block, chunk) pair per workgroup ----
+constexpr int BN_ONE_LAUNCH_ROWS = 256, BN_MAX_CHUNKS = 128;
+
+__host__ __device__ inline int bn_chunk_rows(int m) { const int r = (m + BN_MAX_CHUNKS - 1) / BN_MAX_CHUNKS; return r < 32 ? 32 : r; }
+
+// chunk mean and chunk sum of squared deviations from it: scratch[(2 * chunk) * n + c], scratch[(2 * chunk + 1) * n + c]
+__global__ __launch_bounds__(256) void bn_chunk_stats_kernel(const float* __restrict__ z, int ldz, int m, int n, int rows,
+                                                             float* __restrict__ scratch) {
+  __shared__ float sh[256];
+  const int c = blockIdx.x * BN_COLS + (threadIdx.x & (BN_COLS - 1)), ph = threadIdx.x / BN_COLS;
+  const bool in = c < n;
+  const int r0 = blockIdx.y * rows, r1 = min(m, r0 + rows);
+  float s = 0.f;
+  if (in) for (int r = r0 + ph; r < r1; r += BN_PH) s += z[(size_t)r * ldz + c];
+  const float mean = phase_sum(sh, s) / (float)(r1 - r0);
+  float q = 0.f;
+  if (in) for (int r = r0 + ph; r < r1; r += BN_PH) { const float d = z[(size_t)r * ldz + c] - mean; q += d * d; }
+  q = phase_sum(sh, q);
+  if (in && ph == 0) { scratch[(size_t)(2 * blockIdx.y) * n + c] = mean; scratch[(size_t)(2 * blockIdx.y + 1) * n + c] = q; }
+}
+
+// chunk statistics joined in chunk order (pairwise update of count, mean and sum of squared deviations)
+__global__ void bn_join_stats_kernel(const float* __restrict__ scratch, int m, int n, int rows, int chunks, float eps,
+                                     float* __restrict__ save_mean, float* __restrict__ save_inv_std) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n) return;
+  float cnt = 0.f, mean = 0.f, m2 = 0.f;
+  for (int k = 0; k < chunks; ++k) {
+    const float nb = (float)(min(m, (k + 1) * rows) - k * rows);
+    const float mb = scratch[(size_t)(2 * k) * n + c], qb = scratch[(size_t)(2 * k + 1) * n + c];
+    const float tot = cnt + nb, delta = mb - mean;
+    mean += delta * (nb / tot);
+    m2 += qb + delta * delta * (cnt * nb / tot);
+    cnt = tot;
+  }
+  save_mean[c] = mean;
+  save_inv_std[c] = 1.f / sqrtf(m2 / (float)m + eps);
+}
+
+// the moving statistics as the reference leaves them: mean 0, variance 1
+__global__ void bn_const_stats_kernel(int n, float eps, float* __restrict__ save_mean, float* __restrict__ save_inv_std) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < n) { save_mean[c] = 0.f; save_inv_std[c] = 1.f / sqrtf(1.f + eps); }
+}
+
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ z, int ldz, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, const float* __restrict__ mean_,
+                                                       const float* __restrict__ inv_std_, int m, int n, int rows, int act,
+                                                       float* __restrict__ y, int ldy) {
+  const int c = blockIdx.x * BN_COLS + (threadIdx.x & (BN_COLS - 1)), ph = threadIdx.x / BN_COLS;
+  if (c >= n) return;
+  const int r0 = blockIdx.y * rows, r1 = min(m, r0 + rows);
+  const float mean = mean_[c], inv_std = inv_std_[c], ga = gamma[c], be = beta[c];
+  for (int r = r0 + ph; r < r1; r += BN_PH) {
+    float v = ga * ((z[(size_t)r * ldz + c] - mean) * inv_std) + be;
+    if (act == 3) v = __builtin_amdgcn_fmed3f(v, 0.f, 6.f);
+    y[(size_t)r * ldy + c] = v;
+  }
+}
+
+// per chunk: sum of dyh * xh and of dyh
+__global__ __launch_bounds__(256) void bn_bwd_chunk_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ y, int ldy,
+                                                           const float* __restrict__ z, int ldz, const float* __restrict__ mean_,
+                                                           const float* __restrict__ inv_std_, int m, int n, int rows, int act,
+                                                           float* __restrict__ scratch) {
+  __shared__ float sh[256];
+  const int c = blockIdx.x * BN_COLS + (threadIdx.x & (BN_COLS - 1)), ph = threadIdx.x / BN_COLS;
+  const bool in = c < n;
+  const int r0 = blockIdx.y * rows, r1 = min(m, r0 + rows);
+  const float mean = in ? mean_[c] : 0.f, inv_std = in ? inv_std_[c] : 0.f;
+  float sg = 0.f, sb = 0.f;
+  if (in) {
+    for (int r = r0 + ph; r < r1; r += BN_PH) {
+      float d = dy[(size_t)r * lddy + c];
+      if (act == 3) d *= relu6_d(y[(size_t)r * ldy + c]);
+      sg += d * ((z[(size_t)r * ldz + c] - mean) * inv_std);
+      sb += d;
+    }
+  }
+  const float dg = phase_sum(sh, sg), db = phase_sum(sh, sb);
+  if (in && ph == 0) { scratch[(size_t)(2 * blockIdx.y) * n + c] = dg; scratch[(size_t)(2 * blockIdx.y + 1) * n + c] = db; }
+}
+
+__global__ void bn_bwd_join_kernel(const float* __restrict__ scratch, int n, int chunks, float* __restrict__ dgamma,
+                                   float* __restrict__ dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n) return;
+  float dg = 0.f, db = 0.f;
+  for (int k = 0; k < chunks; ++k) { dg += scratch[(size_t)(2 * k) * n + c]; db += scratch[(size_t)(2 * k + 1) * n + c]; }
+  dgamma[c] = dg; dbeta[c] = db;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ y, int ldy,
+                                                           const float* __restrict__ z, int ldz, const float* __restrict__ gamma,
+                                                           const float* __restrict__ mean_, const float* __restrict__ inv_std_,
+                                                           const float* __restrict__ dgamma, const float* __restrict__ dbeta, int m, int n,
+                                                           int rows, int act, float* __restrict__ dz, int lddz) {
+  const int c = blockIdx.x * BN_COLS + (threadIdx.x & (BN_COLS - 1)), ph = threadIdx.x / BN_COLS;
+  if (c >= n) return;
+  const int r0 = blockIdx.y * rows, r1 = min(m, r0 + rows);
+  const float mean = mean_[c], inv_std = inv_std_[c], k = gamma[c] * inv_std, im = 1.f / (float)m;
+  const float dg = dgamma[c], db = dbeta[c];
+  for (int r = r0 + ph; r < r1; r += BN_PH) {
+    float d = dy[(size_t)r * lddy + c];
+    if (act == 3) d *= relu6_d(y[(size_t)r * ldy + c]);
+    const float xh = (z[(size_t)r * ldz + c] - mean) * inv_std;
+    dz[(size_t)r * lddz + c] = k * (d - db * im - xh * dg * im);
+  }
+}
+
 // one thread per row: label = first index of the row maximum of a (tf.argmax), loss_rows[r] = logsumexp - logit[label],
 // dlogits = (softmax - onehot) / m with the columns from n_classes to ld zeroed
 __global__ void softmax_ce_kernel(const float* __restrict__ logits, int ld, int n_classes, const float* __restrict__ a, int ld_a, int m,
@@ -146,25 +256,58 @@ inline int launched() { return (int)hipGetLastError(); }
 
 extern "C" {
 
+int rlgan_batchnorm_chunks(int m) { return m <= BN_ONE_LAUNCH_ROWS ? 1 : cdiv(m, bn_chunk_rows(m)); }
+
 int rlgan_batchnorm_forward(const float* z, int ldz, const float* gamma, const float* beta, int m, int n, float eps, int training,
-                            int act, float* y, int ldy, float* save_mean, float* save_inv_std, void* stream) {
+                            int act, float* y, int ldy, float* save_mean, float* save_inv_std, float* scratch, void* stream) {
   if (!z || !gamma || !beta || !y || m <= 0 || n <= 0 || (act != 0 && act != 3) || (training && (!save_mean || !save_inv_std)))
     return RLGAN_E_ARG;
   if (ldz < n || ldy < n) return RLGAN_E_ALIGN;
-  hipLaunchKernelGGL(bn_forward_kernel, dim3(cdiv(n, BN_COLS)), dim3(256), 0, (hipStream_t)stream, z, ldz, gamma, beta, m, n, eps,
-                     training, act, y, ldy, save_mean, save_inv_std);
+  const int chunks = rlgan_batchnorm_chunks(m);
+  hipStream_t st = (hipStream_t)stream;
+  if (chunks == 1 || !training) {
+    if (chunks > 1) {                                            // inference over many rows: constant statistics, rows in chunks
+      if (!save_mean || !save_inv_std) return RLGAN_E_ARG;
+      hipLaunchKernelGGL(bn_const_stats_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, n, eps, save_mean, save_inv_std);
+      const int rows = bn_chunk_rows(m);
+      hipLaunchKernelGGL(bn_apply_kernel, dim3(cdiv(n, BN_COLS), chunks), dim3(256), 0, st, z, ldz, gamma, beta, save_mean, save_inv_std, m,
+                         n, rows, act, y, ldy);
+      return launched();
+    }
+    hipLaunchKernelGGL(bn_forward_kernel, dim3(cdiv(n, BN_COLS)), dim3(256), 0, st, z, ldz, gamma, beta, m, n, eps, training, act, y, ldy,
+                       save_mean, save_inv_std);
+    return launched();
+  }
+  if (!scratch) return RLGAN_E_ARG;
+  const int rows = bn_chunk_rows(m);
+  hipLaunchKernelGGL(bn_chunk_stats_kernel, dim3(cdiv(n, BN_COLS), chunks), dim3(256), 0, st, z, ldz, m, n, rows, scratch);
+  hipLaunchKernelGGL(bn_join_stats_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, scratch, m, n, rows, chunks, eps, save_mean, save_inv_std);
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(cdiv(n, BN_COLS), chunks), dim3(256), 0, st, z, ldz, gamma, beta, save_mean, save_inv_std, m, n,
+                     rows, act, y, ldy);
   return launched();
 }
 
 int rlgan_batchnorm_backward(const float* dy, int lddy, const float* y, int ldy, const float* z, int ldz, const float* gamma,
                              const float* save_mean, const float* save_inv_std, int m, int n, int act, float* dz, int lddz,
-                             float* dgamma, float* dbeta, void* stream) {
+                             float* dgamma, float* dbeta, float* scratch, void* stream) {
   if (!dy || !z || !gamma || !save_mean || !save_inv_std || !dz || !dgamma || !dbeta || m <= 0 || n <= 0 || (act != 0 && act != 3) ||
       (act == 3 && !y))
     return RLGAN_E_ARG;
   if (lddy < n || ldz < n || lddz < n || (y && ldy < n)) return RLGAN_E_ALIGN;
-  hipLaunchKernelGGL(bn_backward_kernel, dim3(cdiv(n, BN_COLS)), dim3(256), 0, (hipStream_t)stream, dy, lddy, y, ldy, z, ldz, gamma,
-                     save_mean, save_inv_std, m, n, act, dz, lddz, dgamma, dbeta);
+  const int chunks = rlgan_batchnorm_chunks(m);
+  hipStream_t st = (hipStream_t)stream;
+  if (chunks == 1) {
+    hipLaunchKernelGGL(bn_backward_kernel, dim3(cdiv(n, BN_COLS)), dim3(256), 0, st, dy, lddy, y, ldy, z, ldz, gamma, save_mean,
+                       save_inv_std, m, n, act, dz, lddz, dgamma, dbeta);
+    return launched();
+  }
+  if (!scratch) return RLGAN_E_ARG;
+  const int rows = bn_chunk_rows(m);
+  hipLaunchKernelGGL(bn_bwd_chunk_kernel, dim3(cdiv(n, BN_COLS), chunks), dim3(256), 0, st, dy, lddy, y, ldy, z, ldz, save_mean,
+                     save_inv_std, m, n, rows, act, scratch);
+  hipLaunchKernelGGL(bn_bwd_join_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, scratch, n, chunks, dgamma, dbeta);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(cdiv(n, BN_COLS), chunks), dim3(256), 0, st, dy, lddy, y, ldy, z, ldz, gamma, save_mean,
+                     save_inv_std, dgamma, dbeta, m, n, rows, act, dz, lddz);
   return launched();
 }
 

@@ -40,6 +40,16 @@ class BatchNorm:
         self.canon = torch.from_numpy(np.concatenate([g, b]).astype(np.float32)).to(device())
         self.grad = torch.zeros(2 * n, dtype=torch.float32, device=device())
         self.stats = torch.zeros(2 * n, dtype=torch.float32, device=device())      # batch mean, then 1 / sqrt(var + eps)
+        self._scratch: Optional[torch.Tensor] = None
+
+    def _scratch_ptr(self, m: int):
+        """Per-chunk partial results of a pass over m rows (none for the one-launch form)."""
+        chunks = lib.rlgan_batchnorm_chunks(m)
+        if chunks <= 1:
+            return None
+        if self._scratch is None or self._scratch.numel() < 2 * chunks * self.n:
+            self._scratch = torch.empty(2 * chunks * self.n, dtype=torch.float32, device=device())
+        return self._scratch.data_ptr()
 
     def _ptrs(self, t: torch.Tensor):
         return t.data_ptr(), t.data_ptr() + 4 * self.n
@@ -50,7 +60,8 @@ class BatchNorm:
         ga, be = self._ptrs(self.canon)
         mean, inv = self._ptrs(self.stats)
         check(lib.rlgan_batchnorm_forward(z.data_ptr(), self.n, ga, be, z.shape[0], self.n, BN_EPS, 1 if training else 0,
-                                          3 if relu6 else 0, y.data_ptr(), self.n, mean, inv, _stream()), "rlgan_batchnorm_forward")
+                                          3 if relu6 else 0, y.data_ptr(), self.n, mean, inv, self._scratch_ptr(z.shape[0]), _stream()),
+              "rlgan_batchnorm_forward")
         return y
 
     def backward(self, dy: torch.Tensor, y: torch.Tensor, z: torch.Tensor, relu6: bool) -> torch.Tensor:
@@ -60,7 +71,7 @@ class BatchNorm:
         mean, inv = self._ptrs(self.stats)
         dga, dbe = self._ptrs(self.grad)
         check(lib.rlgan_batchnorm_backward(dy.data_ptr(), self.n, y.data_ptr(), self.n, z.data_ptr(), self.n, ga, mean, inv, z.shape[0],
-                                           self.n, 3 if relu6 else 0, dz.data_ptr(), self.n, dga, dbe, _stream()),
+                                           self.n, 3 if relu6 else 0, dz.data_ptr(), self.n, dga, dbe, self._scratch_ptr(z.shape[0]), _stream()),
               "rlgan_batchnorm_backward")
         return dz
 

@@ -86,3 +86,33 @@ def test_inverse_model_learns_the_actions():
     for _ in range(60):
         M.learn(T["s"], T["s_next"], T["a"])
     assert float(M.learn(T["s"], T["s_next"], T["a"]).item()) < 0.5 * l0
+
+
+@pytest.mark.parametrize("m,n", [(7, 100), (256, 500), (1000, 500), (4101, 8), (20000, 100)])
+def test_batchnorm_kernels(m, n):
+    """Both forms of the batch-norm kernels (one launch up to 256 rows, row chunks above) against the restatement, with a
+    column mean far from zero: forward in both modes, and the gradient of the training form."""
+    import rl_gan_amd as R
+    from gpu_util import close
+    from oracle import inverse_model as om
+    rng = np.random.RandomState(m + n)
+    f32 = lambda v: np.asarray(v).astype(np.float32).astype(np.float64)
+    z = f32(rng.standard_normal((m, n)) * rng.uniform(0.5, 2, n) + rng.uniform(-20, 20, n))
+    gamma, beta = f32(rng.uniform(0.5, 1.5, n)), f32(rng.uniform(0, 3, n))
+    dy = f32(rng.standard_normal((m, n)))
+    bn = R.BatchNorm(n, gamma, beta)
+    zt, dyt = torch.from_numpy(z.astype(np.float32)).cuda(), torch.from_numpy(dy.astype(np.float32)).cuda()
+    want_inf, _ = om.bn_forward(z, gamma, beta, training=False)
+    close(bn.forward(zt, False, True).cpu().numpy(), om.relu6(want_inf), what="inference")
+    for relu6 in (False, True):
+        want, cache = om.bn_forward(z, gamma, beta, training=True)
+        y = bn.forward(zt, True, relu6)
+        close(y.cpu().numpy(), om.relu6(want) if relu6 else want, what=f"training relu6={relu6}")
+        close(bn.stats.cpu().numpy()[:n], z.mean(0), what="batch mean")
+        close(bn.stats.cpu().numpy()[n:], 1 / np.sqrt(z.var(0) + om.EPS), what="1/std")
+        d = dy * ((want > 0) & (want < 6)) if relu6 else dy
+        dz, dg, db = om.bn_backward(d, cache)
+        got = bn.backward(dyt, y, zt, relu6)
+        close(bn.grad.cpu().numpy()[:n], dg, what="dgamma", atol=1e-5 * np.abs(d).sum(0).max())
+        close(bn.grad.cpu().numpy()[n:], db, what="dbeta", atol=1e-5 * np.abs(d).sum(0).max())
+        close(got.cpu().numpy(), dz, what="dz", atol=1e-5 * np.abs(dz).max())

@@ -42,3 +42,25 @@ for B in [int(v) for v in sys.argv[1:]] or [32, 4096]:
           f" = {B / tgph * 1e6:9.0f} transitions/s")
     print(f"B={B:5d}: generator.learn {tg:9.1f} us   discriminator.learn {td:9.1f} us   predict_batch {tp:8.1f} us   determine_batch {tr:8.1f} us"
           f"   ({B / (tg + td) * 1e6:9.0f} transitions/s through both steps)")
+    # the rest of the reference's learning iteration (Curious_GAN_mario.py:96-98): inverse model, critic, actor
+    A_pred = R.StateActionPredictor(a_dim, 1e-4, st, rng=rng)
+    actor = R.PixelActor(a_dim, 1e-4, 1100, st, rng=rng)
+    critic = R.PixelCritic(a_dim, 1e-4, 0.99, 1000, actor, st, rng=rng)
+    s, s_next = mem.gather(idx, "s"), mem.gather(idx, "s_")
+    r = torch.rand(B, 1, device="cuda")
+    phis_next = st.forward(s_next).clone()
+    ta = timeit(lambda: A_pred.learn(s, s_next, a))
+    tc = timeit(lambda: critic.learn(None, a, r, None, phis=phis, phis_next=phis_next))
+    tac = timeit(lambda: actor.learn(None, critic, phis=phis))
+    scal = R.DeviceMemory(mem.capacity + 1, a_dim + 2)
+    for i in range(0, mem.capacity + 1, 4096):
+        k = min(4096, mem.capacity + 1 - i)
+        scal.store_rows(torch.rand(k, a_dim + 2, device="cuda") * 2 - 1)
+    full = R.PixelGanTrainer(mem, scal, G, D, B, a_pred=A_pred, actor=actor, critic=critic)
+    full.sample()
+    tfe = timeit(full.step)
+    full.capture()
+    tfg = timeit(lambda: (full.sample(), full.step()))
+    print(f"B={B:5d}: A_pred.learn {ta:9.1f} us   critic.learn (features given) {tc:8.1f} us   actor.learn (features given) {tac:8.1f} us")
+    print(f"B={B:5d}: whole learning iteration (GAN half + inverse model + critic + actor): one by one {tfe:9.1f} us, as a graph {tfg:9.1f} us"
+          f" = {B / tfg * 1e6:9.0f} transitions/s")
