@@ -506,6 +506,13 @@ int rlgan_act_backward(const float* dy, const float* y, float* dz, int64_t n, in
 int rlgan_td_error(const float* q, const float* q_next, int ld, const float* reward, float gamma, int m, float* parts, float* dq,
                    void* stream);
 
+/* State update of tf.contrib.rnn.BasicLSTMCell (the `lstm_unit` of the pixel actor, Conv_model.py:67-99) from the gate
+ * pre-activations gates[m][4 * units] = [x, h] * kernel + bias (rlgan_dense_forward), TensorFlow's gate order i, j, f, o:
+ * c_out = c_in * sigmoid(f + forget_bias) + sigmoid(i) * tanh(j), h_out = tanh(c_out) * sigmoid(o); forget_bias is 1 in
+ * the reference (the cell's default).  c_in, c_out, h_out: dense [m][units]. */
+int rlgan_lstm_gates(const float* gates, const float* c_in, int m, int units, float forget_bias, float* c_out, float* h_out,
+                     void* stream);
+
 #ifdef __cplusplus
 }
 #endif

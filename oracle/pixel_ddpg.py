@@ -82,3 +82,12 @@ def actor_policy_grads(phis, A_eval, C_eval):
     q, ccache = critic_forward(phis, a, C_eval)
     da, _ = critic_backward(np.ones_like(q), C_eval, ccache)
     return a, da, actor_backward(da, A_eval, acache)
+
+
+def lstm_step(x, c, h, kernel, bias, forget_bias=1.0):
+    """One step of tf.contrib.rnn.BasicLSTMCell (Conv_model.py:80-91): gates = [x, h] kernel + bias in the order
+    i, j, f, o; c' = c sigmoid(f + forget_bias) + sigmoid(i) tanh(j); h' = tanh(c') sigmoid(o).  Returns (c', h')."""
+    sig = lambda v: 1.0 / (1.0 + np.exp(-v))
+    i, j, f, o = np.split(np.concatenate([x, h], 1) @ kernel + bias, 4, axis=1)
+    c2 = c * sig(f + forget_bias) + sig(i) * np.tanh(j)
+    return c2, np.tanh(c2) * sig(o)

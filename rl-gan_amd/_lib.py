@@ -189,6 +189,7 @@ PROTOTYPES = {
     "rlgan_batchnorm_backward": [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp],
     "rlgan_act_backward": [_vp, _vp, _vp, C.c_int64, _i, _vp],
     "rlgan_td_error": [_vp, _vp, _i, _vp, _f, _i, _vp, _vp, _vp],
+    "rlgan_lstm_gates": [_vp, _vp, _i, _i, _f, _vp, _vp, _vp],
     "rlgan_softmax_ce": [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp],
     "rlgan_mse": [_vp, _vp, C.c_int64, _vp, _vp, _vp],
     "rlgan_conv_forward_u8": [C.POINTER(Conv), _vp, C.c_int64, _vp, _f, _vp, _vp, _i, _i, _vp],

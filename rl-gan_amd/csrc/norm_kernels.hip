@@ -250,6 +250,21 @@ __global__ __launch_bounds__(256) void td_error_kernel(const float* __restrict__
   if (threadIdx.x == 0) parts[blockIdx.x] = ((sh[0] + sh[1]) + sh[2]) + sh[3];
 }
 
+// tf.contrib.rnn.BasicLSTMCell state update from the gate pre-activations [m][4u] in TensorFlow's order i, j, f, o:
+// c' = c * sigmoid(f + forget_bias) + sigmoid(i) * tanh(j);  h' = tanh(c') * sigmoid(o)
+__global__ void lstm_gates_kernel(const float* __restrict__ gates, const float* __restrict__ c_in, int m, int u, float forget_bias,
+                                  float* __restrict__ c_out, float* __restrict__ h_out) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (size_t)m * u) return;
+  const size_t r = t / u, k = t - r * u;
+  const float* g = gates + r * 4 * (size_t)u;
+  const float i = g[k], j = g[u + k], f = g[2 * u + k], o = g[3 * u + k];
+  const float sig_i = 1.f / (1.f + expf(-i)), sig_f = 1.f / (1.f + expf(-(f + forget_bias))), sig_o = 1.f / (1.f + expf(-o));
+  const float c = c_in[t] * sig_f + sig_i * tanhf(j);
+  c_out[t] = c;
+  h_out[t] = tanhf(c) * sig_o;
+}
+
 inline int launched() { return (int)hipGetLastError(); }
 
 }  // namespace
@@ -330,6 +345,15 @@ int rlgan_td_error(const float* q, const float* q_next, int ld, const float* rew
                    void* stream) {
   if (!q || !q_next || !reward || !parts || m <= 0 || ld <= 0) return RLGAN_E_ARG;
   hipLaunchKernelGGL(td_error_kernel, dim3(cdiv(m, 256)), dim3(256), 0, (hipStream_t)stream, q, q_next, ld, reward, gamma, m, parts, dq);
+  return launched();
+}
+
+int rlgan_lstm_gates(const float* gates, const float* c_in, int m, int units, float forget_bias, float* c_out, float* h_out,
+                     void* stream) {
+  if (!gates || !c_in || !c_out || !h_out || m <= 0 || units <= 0) return RLGAN_E_ARG;
+  const size_t n = (size_t)m * units;
+  hipLaunchKernelGGL(lstm_gates_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, gates, c_in, m, units,
+                     forget_bias, c_out, h_out);
   return launched();
 }
 

@@ -89,6 +89,52 @@ class _Net:
         return d
 
 
+class LSTMUnit:
+    """`lstm_unit` (Conv_model.py:67-99): one step of tf.contrib.rnn.BasicLSTMCell(n_lstm_unit) on the state encoder's
+    features, state (c, h) in and out.  With USE_LSTM False (Conv_model.py:667) the loop only carries this state along and
+    stores it with every transition (Curious_GAN_mario.py:69,75); the cell's variables get no gradient.  Parameters in
+    canonical order: kernel [features + units, 4 units] (gate order i, j, f, o), then the bias."""
+
+    FORGET_BIAS = 1.0                                            # BasicLSTMCell default
+
+    def __init__(self, state_encoder: ConvEncoder, n_lstm_unit: Optional[int] = None, rng: Optional[np.random.RandomState] = None,
+                 kernel: Optional[np.ndarray] = None, bias: Optional[np.ndarray] = None):
+        rng = rng or np.random.RandomState()
+        self.state_encoder = state_encoder
+        self.h_dim = state_encoder.features
+        self.units = int(n_lstm_unit or self.h_dim)              # Conv_model.py:685: n_lstm_unit = phis.shape[1]
+        k = self.h_dim + self.units
+        if kernel is None:                                       # the scope's default initializer (glorot uniform), zero bias
+            kernel, bias = _xavier(rng, k, 4 * self.units), np.zeros(4 * self.units)
+        self.cell = DenseLayer(k, 4 * self.units, kernel=kernel, bias=np.asarray(bias).reshape(-1))
+
+    def get_initial_state(self):
+        """[c, h], each zeros [1, units] (Conv_model.py:75-77,98-99)."""
+        return [np.zeros((1, self.units), np.float32), np.zeros((1, self.units), np.float32)]
+
+    def step_batch(self, phis: torch.Tensor, c_in: torch.Tensor, h_in: torch.Tensor):
+        """(c', h') for a batch of features and states, all on the device."""
+        n = phis.shape[0]
+        x = torch.empty((n, self.h_dim + self.units), dtype=torch.float32, device=phis.device)
+        check(lib.rlgan_copy_cols(phis.data_ptr(), phis.stride(0), x.data_ptr(), x.shape[1], n, self.h_dim, 0, _stream()), "rlgan_copy_cols")
+        check(lib.rlgan_copy_cols(h_in.data_ptr(), h_in.stride(0), x.data_ptr() + 4 * self.h_dim, x.shape[1], n, self.units, 0, _stream()),
+              "rlgan_copy_cols")
+        gates = self.cell.forward(x, act=False)
+        c_in = c_in.contiguous()
+        c_out, h_out = torch.empty_like(c_in), torch.empty_like(c_in)
+        check(lib.rlgan_lstm_gates(gates.data_ptr(), c_in.data_ptr(), n, self.units, self.FORGET_BIAS, c_out.data_ptr(), h_out.data_ptr(),
+                                   _stream()), "rlgan_lstm_gates")
+        return c_out, h_out
+
+    def get_state(self, s, lstm_state):
+        """[c', h'] as NumPy arrays [1, units] for a single state [h, w, c] (Conv_model.py:93-96)."""
+        s = torch.as_tensor(np.asarray(s, dtype=np.float32)[None], device=device())
+        c = torch.as_tensor(np.asarray(lstm_state[0], dtype=np.float32).reshape(1, -1), device=device())
+        h = torch.as_tensor(np.asarray(lstm_state[1], dtype=np.float32).reshape(1, -1), device=device())
+        c2, h2 = self.step_batch(self.state_encoder.forward(s), c, h)
+        return [c2.cpu().numpy(), h2.cpu().numpy()]
+
+
 ACTOR_KEYS = ("w1", "b1", "w2", "b2", "w3", "b3", "wa", "ba")
 CRITIC_KEYS = ("w1_s", "w1_a", "b1", "w2", "b2", "w3", "b3", "wq", "bq")
 
@@ -106,6 +152,8 @@ class PixelActor:
         self.t_replace_counter = torch.zeros(1, dtype=torch.int32, device=device())
         self._opt = [_RMSProp(e, t) for e, t in zip(self.eval_net.layers, self.target_net.layers)]
         self._acts: Optional[List[torch.Tensor]] = None
+        self.LSTM_unit = LSTMUnit(state_encoder, rng=rng)        # Conv_model.py:685-686,693-694
+        self.LSTM_unit_ = LSTMUnit(state_encoder, rng=rng)
 
     def _build(self, rng, P) -> _Net:
         h, ad = self.h_dim, self.a_dim

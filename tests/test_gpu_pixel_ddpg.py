@@ -157,6 +157,14 @@ def test_steps_from_frames_and_action_choice():
     noisy = np.random.normal(od.actor_forward(phis[:1], A)[0], 0.3)
     want = np.zeros(ad, dtype=np.int64); want[noisy.argmax(axis=1)] = 1
     assert np.array_equal(got, want) and got.sum() == 1
+    # the state path (Curious_GAN_mario.py:69): two steps from the initial state on the first frame stack
+    unit = actor.LSTM_unit
+    kern, bias = unit.cell.kernel_bias()
+    st_o, st_d = [np.zeros((1, H)), np.zeros((1, H))], unit.get_initial_state()
+    for _ in range(2):
+        st_o = list(od.lstm_step(phis[:1], st_o[0], st_o[1], kern.astype(np.float64), bias.astype(np.float64)))
+        st_d = unit.get_state(s[0], st_d)
+    close(st_d[0], st_o[0], what="lstm c"); close(st_d[1], st_o[1], what="lstm h")
     got_loss = float(critic.learn(_dev(s), _dev(a), _dev(r), _dev(s_n)).item())
     assert abs(got_loss - loss) <= 1e-5 * loss
     g2 = critic.eval_net.layers[1].grad.cpu().numpy()
@@ -174,3 +182,20 @@ def test_steps_from_frames_and_action_choice():
     close(g1[:H * 200].reshape(H, 200), Ga["w1"], what="actor dw1 from frames")
     for L, w0 in zip(enc.layers + [enc.head], enc_before):       # neither step trains the encoder
         assert torch.equal(L.canon, w0)
+
+
+@pytest.mark.parametrize("n", [1, 33])
+def test_lstm_state_step(n):
+    """The state path of the pixel actor (`lstm_unit.get_state`, Conv_model.py:67-99) against the restatement."""
+    import rl_gan_amd as R
+    from gpu_util import close
+    from oracle import pixel_ddpg as od
+    rng = np.random.RandomState(n)
+    kernel, bias = _f32(rng.uniform(-0.08, 0.08, (2 * H, 4 * H))), _f32(rng.uniform(-0.2, 0.2, 4 * H))
+    unit = R.LSTMUnit(_Enc(), kernel=kernel, bias=bias)
+    phis, c, h = _f32(rng.uniform(0, 2, (n, H))), _f32(rng.standard_normal((n, H))), _f32(rng.uniform(-1, 1, (n, H)))
+    c2, h2 = od.lstm_step(phis, c, h, kernel, bias)
+    gc, gh = unit.step_batch(_dev(phis), _dev(c), _dev(h))
+    close(gc.cpu().numpy(), c2, what="c'"); close(gh.cpu().numpy(), h2, what="h'")
+    init = unit.get_initial_state()
+    assert len(init) == 2 and init[0].shape == (1, H) and not init[0].any() and not init[1].any()

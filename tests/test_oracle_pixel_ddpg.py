@@ -61,3 +61,23 @@ def test_policy_gradient_against_torch_autograd():
     for k in A:
         np.testing.assert_allclose(G[k], Ae[k].grad.numpy().reshape(G[k].shape), rtol=1e-9, atol=1e-13, err_msg=k)
     assert np.abs(da).max() > 0 and (np.abs(od.actor_forward(phis, A)[1][5]) > 0).any()
+
+
+def test_lstm_step_against_torch_cell():
+    """torch.nn.LSTMCell orders its gates i, f, g, o and has no forget bias: TensorFlow's kernel is re-ordered and the
+    forget bias folded into the bias to compare."""
+    rng = np.random.RandomState(2)
+    n, k, u = 5, 12, 8
+    kernel, bias = rng.uniform(-0.4, 0.4, (k + u, 4 * u)), rng.uniform(-0.2, 0.2, 4 * u)
+    x, c, h = rng.standard_normal((n, k)), rng.standard_normal((n, u)), rng.uniform(-1, 1, (n, u))
+    c2, h2 = od.lstm_step(x, c, h, kernel, bias)
+    i, j, f, o = np.split(kernel, 4, axis=1)
+    bi, bj, bf, bo = np.split(bias, 4)
+    cell = torch.nn.LSTMCell(k, u).double()
+    W = np.concatenate([i, f, j, o], 1)                              # torch: i, f, g (= j), o
+    with torch.no_grad():
+        cell.weight_ih.copy_(torch.tensor(W[:k].T)); cell.weight_hh.copy_(torch.tensor(W[k:].T))
+        cell.bias_ih.copy_(torch.tensor(np.concatenate([bi, bf + 1.0, bj, bo]))); cell.bias_hh.zero_()
+        ht, ct = cell(torch.tensor(x), (torch.tensor(h), torch.tensor(c)))
+    np.testing.assert_allclose(c2, ct.numpy(), rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(h2, ht.numpy(), rtol=1e-12, atol=1e-12)
