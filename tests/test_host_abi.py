@@ -145,3 +145,30 @@ def test_missing_library_fails_loudly(tmp_path):
     (pkg / "_lib.py").write_text(open(os.path.join(ROOT, "rl-gan_amd", "_lib.py")).read())
     r = subprocess.run([sys.executable, "-c", "import pkg._lib"], cwd=tmp_path, capture_output=True, text=True)
     assert r.returncode != 0 and "no CPU fallback" in r.stderr
+
+
+def test_batchnorm_chunks_cover_the_rows():
+    """One launch up to 256 rows; above that at most 128 chunks of at least 32 rows whose union is the batch."""
+    f = _lib.lib.rlgan_batchnorm_chunks
+    assert [f(m) for m in (1, 32, 256)] == [1, 1, 1]
+    for m in (257, 1000, 4096, 4101, 1 << 20):
+        ch = f(m)
+        rows = max(32, -(-m // 128))
+        assert 1 < ch <= 128 and ch == -(-m // rows) and rows * ch >= m > rows * (ch - 1)
+
+
+def test_argument_errors_of_the_pixel_entry_points():
+    """Checked on the host before anything is launched: missing pointers and sizes that do not fit."""
+    L = _lib.lib
+    p = 256                                                # stands for a device address; never dereferenced on these paths
+    assert L.rlgan_batchnorm_forward(None, 8, p, p, 4, 8, 1e-3, 1, 0, p, 8, p, p, None, None) == -1
+    assert L.rlgan_batchnorm_forward(p, 8, p, p, 4, 8, 1e-3, 1, 0, p, 8, None, p, None, None) == -1      # training needs save_mean
+    assert L.rlgan_batchnorm_forward(p, 8, p, p, 4, 8, 1e-3, 1, 5, p, 8, p, p, None, None) == -1         # unknown activation
+    assert L.rlgan_batchnorm_forward(p, 4, p, p, 4, 8, 1e-3, 1, 0, p, 8, p, p, None, None) < 0           # ld < n
+    assert L.rlgan_batchnorm_forward(p, 8, p, p, 1000, 8, 1e-3, 1, 0, p, 8, p, p, None, None) == -1      # chunks > 1 without scratch
+    assert L.rlgan_batchnorm_backward(p, 8, None, 8, p, 8, p, p, p, 4, 8, 3, p, 8, p, p, None, None) == -1   # relu6 needs y
+    assert L.rlgan_softmax_ce(p, 4, 6, p, 6, 3, p, None, None) < 0                                       # ld < n_classes
+    assert L.rlgan_td_error(p, p, 4, None, 0.99, 8, p, p, None) == -1
+    assert L.rlgan_act_backward(p, p, p, 10, 1, None) == -1                                              # relu6 / tanh only
+    assert L.rlgan_lstm_gates(p, p, 0, 256, 1.0, p, p, None) == -1
+    assert L.rlgan_dense_forward(p, 8, p, p, 8, 4, 8, 8, 5, None, 1, None) == -1                         # activation codes 0..4
