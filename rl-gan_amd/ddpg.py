@@ -13,7 +13,7 @@ import torch
 from . import _lib
 from .core import DeviceNet, device, mlp_forward
 from .engine import ActorState, CriticState
-from .replay import DeviceMemory
+from .replay import DeviceMemory, device_view
 from .session import Placeholder, Session, TensorHandle, init_rng
 
 
@@ -22,6 +22,8 @@ def _dev(x, width: Optional[int] = None) -> torch.Tensor:
     applies when a float64 batch is fed to a float32 placeholder."""
     if isinstance(x, torch.Tensor):
         t = x.to(device=device(), dtype=torch.float32)
+    elif (t := device_view(x)) is not None:                 # a slice of the minibatch `Memory.sample` just returned
+        return t
     else:
         t = torch.from_numpy(np.ascontiguousarray(np.asarray(x, dtype=np.float32))).to(device())
     if t.dim() == 1:

@@ -107,8 +107,32 @@ class DeviceMemory:
         return self.gather(self.sample_indices(n))
 
     def sample(self, n: int) -> np.ndarray:
-        """[n, dims] float64 host array, like the reference's `data[indices, :]`."""
-        return self.sample_device(n).cpu().numpy().astype(np.float64)
+        """[n, dims] float64 host array, like the reference's `data[indices, :]`.  The rows stay on the device as
+        well: column slices of the returned array (`b_M[:, :state_dim]`, Curious_GAN.py:201-205) handed to a `learn`
+        or `eval` call are recognised by `device_view` and served from there instead of being uploaded again.  The
+        array is read-only so that those device rows cannot go stale."""
+        global _LAST_SAMPLE
+        dev = self.sample_device(n)
+        host = dev.cpu().numpy().astype(np.float64)
+        host.flags.writeable = False
+        _LAST_SAMPLE = (host, dev)
+        return host
+
+
+_LAST_SAMPLE = None                                             # (host array, device rows) of the newest `sample` call
+
+
+def device_view(x) -> Optional[torch.Tensor]:
+    """The device copy of `x` when x is a column slice (all rows) of the newest sampled minibatch, else None."""
+    if _LAST_SAMPLE is None or not isinstance(x, np.ndarray):
+        return None
+    host, dev = _LAST_SAMPLE
+    if x is host:
+        return dev
+    if x.base is not host or x.ndim != 2 or x.shape[0] != host.shape[0] or x.strides != host.strides:
+        return None
+    c0 = (x.__array_interface__["data"][0] - host.__array_interface__["data"][0]) // host.itemsize
+    return dev[:, c0:c0 + x.shape[1]]
 
 
 class FrameMemory:

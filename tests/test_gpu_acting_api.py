@@ -241,3 +241,39 @@ def test_reference_training_loops_and_checkpoint_round_trip(tmp_path):
         np.testing.assert_array_equal(a.get_flat(), b2.get_flat())
     h2 = R.train_DDPG(R.Agent(cfg), episodes=2, log=None)
     assert len(h2) == 2 and all(np.isfinite(h["R"]) for h in h2)
+
+
+def test_minibatch_slices_are_served_from_the_device_copy():
+    """Column slices of the array `Memory.sample` returns reach the kernels without a second upload: the training
+    loop is bit-identical to one that hands over copies of the slices (which take the upload path), and an array
+    that is not such a slice is never mistaken for one."""
+    import rl_gan_amd as R
+    from rl_gan_amd.replay import device_view
+    finals = []
+    for copies in (False, True):
+        R.set_random_seed(3); np.random.seed(3)
+        ag = R.Agent(R.Settings(MEMORY_CAPACITY=60, BATCH_SIZE=16, MAX_EP_STEPS=40, SEED=3))
+        R.train(ag, episodes=2, log=None)                                   # fills the ring, a few updates
+        for _ in range(5):
+            b_M = ag.M.sample(16)
+            b_s, b_s_, b_g, b_a, b_r = b_M[:, :7], b_M[:, 7:14], b_M[:, 14:21], b_M[:, -4:-2], b_M[:, -1:]
+            if not copies:
+                for v, c0 in ((b_s, 0), (b_s_, 7), (b_g, 14), (b_a, 21), (b_r, 24)):
+                    d = device_view(v)
+                    assert d is not None and d.shape == v.shape
+                    np.testing.assert_array_equal(d.cpu().numpy().astype(np.float64), v)
+                assert device_view(b_M[:8, :7]) is None and device_view(b_M[:, :7].copy()) is None and device_view(b_M[:, ::2]) is None
+                with pytest.raises(ValueError):
+                    b_M[0, 0] = 1.0                                          # read-only: the device rows cannot go stale
+            else:
+                b_s, b_s_, b_g, b_a, b_r = (v.copy() for v in (b_s, b_s_, b_g, b_a, b_r))
+                assert all(device_view(v) is None for v in (b_s, b_s_, b_g, b_a, b_r))
+            ag.critic.learn(b_s, b_a, b_r, b_s_)
+            ag.actor.learn(b_s)
+            ag.discriminator.learn(b_g, b_s_, b_s, b_a)
+            ag.generator.learn(b_s, b_a)
+            d_loss, g_loss = ag.discriminator.eval(b_g, b_s_, b_s, b_a), ag.generator.eval(b_s, b_a)
+        finals.append((d_loss, g_loss, {k: v.copy() for k, v in ag.variables().items()}))
+    assert finals[0][0] == finals[1][0] and finals[0][1] == finals[1][1]
+    for k, v in finals[0][2].items():
+        np.testing.assert_array_equal(v, finals[1][2][k], err_msg=k)
