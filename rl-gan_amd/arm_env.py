@@ -66,6 +66,11 @@ class ArmEnv(object):
     def __init__(self, mode='easy'):
         self.mode = mode
         self._v = VecArmEnv(1, mode)
+        # state, reward and done of the one environment side by side, so that a step reads them back in one transfer
+        self._out = torch.zeros(80, dtype=torch.uint8, device=device())
+        self._v.state64 = self._out[:56].view(torch.float64).view(1, 7)
+        self._v.reward = self._out[56:64].view(torch.float64)
+        self._v.done = self._out[64:65]
 
     # state mirrors of the reference attributes
     @property
@@ -90,8 +95,10 @@ class ArmEnv(object):
 
     def step(self, action):
         a = torch.from_numpy(np.asarray(action, dtype=np.float64).reshape(1, 2)).to(device())
-        s, r, d = self._v.step(a)
-        return s.cpu().numpy()[0], float(r.item()), bool(d.item())
+        self._v.step(a)
+        out = self._out.cpu().numpy()
+        f = out[:64].view(np.float64)
+        return f[:7].copy(), float(f[7]), bool(out[64])
 
     def reset(self):
         u = torch.from_numpy(np.random.rand(2).reshape(1, 2)).to(device())   # the global stream, like arm_env.py:66,69
