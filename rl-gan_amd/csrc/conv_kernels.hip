@@ -571,24 +571,27 @@ __global__ __launch_bounds__(256) void conv_wgrad_small_kernel(const ConvG g, co
 // 16 partial sums are added in a fixed order, so the result does not depend on timing.
 __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __restrict__ slabs, int n_slabs, int KP, int NP,
                                                                 int K, int Cout, float* __restrict__ grad) {
-  __shared__ float part[16][17];
-  const int e = threadIdx.x >> 4, j = threadIdx.x & 15;
-  const int i = blockIdx.x * 16 + e;
+  // 64 consecutive gradient entries per workgroup (neighbouring lanes read neighbouring floats of a slab), four
+  // slab phases per entry, each with four loads in flight; the phases meet in LDS and are added in phase order
+  __shared__ float part[4][64];
+  const int col = threadIdx.x & 63, ph = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + col;
   const int total = (K + 1) * Cout;
   float s = 0.f;
   if (i < total) {
     const int k = i / Cout, n = i - k * Cout;
     const float* p = slabs + (size_t)k * NP + n;
-    for (int q = j; q < n_slabs; q += 16) s += p[(size_t)q * KP * NP];
+    const size_t st = (size_t)KP * NP;
+    int q = ph;
+    for (; q + 12 < n_slabs; q += 16) {
+      const float a = p[(size_t)q * st], b = p[(size_t)(q + 4) * st], c = p[(size_t)(q + 8) * st], d = p[(size_t)(q + 12) * st];
+      s += a; s += b; s += c; s += d;
+    }
+    for (; q < n_slabs; q += 4) s += p[(size_t)q * st];
   }
-  part[e][j] = s;
+  part[ph][col] = s;
   __syncthreads();
-  if (j == 0 && i < total) {
-    float t = 0.f;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) t += part[e][q];
-    grad[i] = t;
-  }
+  if (ph == 0 && i < total) grad[i] = ((part[0][col] + part[1][col]) + part[2][col]) + part[3][col];
 }
 
 // fragment images of the input-gradient classes: offsets and total size (0 when the layer is outside
@@ -658,7 +661,7 @@ int launch_wgrad(const ConvG& g, const S& src, const float* dz, const float* y_e
       hipLaunchKernelGGL((conv_wgrad_small_kernel<2, 8, S>), grid, block, lds, st, g, src, dz, y_elu, slabs, M, per);
     }
     if (const int rc = launched()) return rc;
-    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(cdiv((g.K + 1) * g.Cout, 16)), dim3(256), 0, st, slabs, used, KP, NP, g.K, g.Cout, grad);
+    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(cdiv((g.K + 1) * g.Cout, 64)), dim3(256), 0, st, slabs, used, KP, NP, g.K, g.Cout, grad);
     return launched();
   }
   const int per = cdiv(cdiv(M, n_slabs), WG_PIX) * WG_PIX;  // pixels per workgroup, a multiple of the staging step
@@ -680,7 +683,7 @@ int launch_wgrad(const ConvG& g, const S& src, const float* dz, const float* y_e
   }
 #undef RLGAN_WG
   if (const int rc = launched()) return rc;
-  hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(cdiv((g.K + 1) * g.Cout, 16)), dim3(256), 0, st, slabs, used, KP, NP, g.K, g.Cout, grad);
+  hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(cdiv((g.K + 1) * g.Cout, 64)), dim3(256), 0, st, slabs, used, KP, NP, g.K, g.Cout, grad);
   return launched();
 }
 

@@ -112,13 +112,24 @@ __global__ void bn_join_stats_kernel(const float* __restrict__ scratch, int m, i
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= n) return;
   float cnt = 0.f, mean = 0.f, m2 = 0.f;
-  for (int k = 0; k < chunks; ++k) {
-    const float nb = (float)(min(m, (k + 1) * rows) - k * rows);
-    const float mb = scratch[(size_t)(2 * k) * n + c], qb = scratch[(size_t)(2 * k + 1) * n + c];
-    const float tot = cnt + nb, delta = mb - mean;
-    mean += delta * (nb / tot);
-    m2 += qb + delta * delta * (cnt * nb / tot);
-    cnt = tot;
+  for (int k0 = 0; k0 < chunks; k0 += 8) {               // eight chunks' loads in flight, then the dependent updates
+    float mb[8], qb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = min(k0 + j, chunks - 1);
+      mb[j] = scratch[(size_t)(2 * k) * n + c]; qb[j] = scratch[(size_t)(2 * k + 1) * n + c];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = k0 + j;
+      if (k < chunks) {
+        const float nb = (float)(min(m, (k + 1) * rows) - k * rows);
+        const float tot = cnt + nb, delta = mb[j] - mean;
+        mean += delta * (nb / tot);
+        m2 += qb[j] + delta * delta * (cnt * nb / tot);
+        cnt = tot;
+      }
+    }
   }
   save_mean[c] = mean;
   save_inv_std[c] = 1.f / sqrtf(m2 / (float)m + eps);
@@ -173,7 +184,16 @@ __global__ void bn_bwd_join_kernel(const float* __restrict__ scratch, int n, int
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= n) return;
   float dg = 0.f, db = 0.f;
-  for (int k = 0; k < chunks; ++k) { dg += scratch[(size_t)(2 * k) * n + c]; db += scratch[(size_t)(2 * k + 1) * n + c]; }
+  for (int k0 = 0; k0 < chunks; k0 += 8) {               // eight chunks' loads in flight, added in chunk order
+    float a[8], b[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = min(k0 + j, chunks - 1);
+      a[j] = scratch[(size_t)(2 * k) * n + c]; b[j] = scratch[(size_t)(2 * k + 1) * n + c];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) if (k0 + j < chunks) { dg += a[j]; db += b[j]; }
+  }
   dgamma[c] = dg; dbeta[c] = db;
 }
 
@@ -296,7 +316,7 @@ int rlgan_batchnorm_forward(const float* z, int ldz, const float* gamma, const f
   if (!scratch) return RLGAN_E_ARG;
   const int rows = bn_chunk_rows(m);
   hipLaunchKernelGGL(bn_chunk_stats_kernel, dim3(cdiv(n, BN_COLS), chunks), dim3(256), 0, st, z, ldz, m, n, rows, scratch);
-  hipLaunchKernelGGL(bn_join_stats_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, scratch, m, n, rows, chunks, eps, save_mean, save_inv_std);
+  hipLaunchKernelGGL(bn_join_stats_kernel, dim3(cdiv(n, 64)), dim3(64), 0, st, scratch, m, n, rows, chunks, eps, save_mean, save_inv_std);
   hipLaunchKernelGGL(bn_apply_kernel, dim3(cdiv(n, BN_COLS), chunks), dim3(256), 0, st, z, ldz, gamma, beta, save_mean, save_inv_std, m, n,
                      rows, act, y, ldy);
   return launched();
@@ -320,7 +340,7 @@ int rlgan_batchnorm_backward(const float* dy, int lddy, const float* y, int ldy,
   const int rows = bn_chunk_rows(m);
   hipLaunchKernelGGL(bn_bwd_chunk_kernel, dim3(cdiv(n, BN_COLS), chunks), dim3(256), 0, st, dy, lddy, y, ldy, z, ldz, save_mean,
                      save_inv_std, m, n, rows, act, scratch);
-  hipLaunchKernelGGL(bn_bwd_join_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, scratch, n, chunks, dgamma, dbeta);
+  hipLaunchKernelGGL(bn_bwd_join_kernel, dim3(cdiv(n, 64)), dim3(64), 0, st, scratch, n, chunks, dgamma, dbeta);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(cdiv(n, BN_COLS), chunks), dim3(256), 0, st, dy, lddy, y, ldy, z, ldz, gamma, save_mean,
                      save_inv_std, dgamma, dbeta, m, n, rows, act, dz, lddz);
   return launched();
