@@ -49,7 +49,10 @@ def measured_hbm_traffic(kernel):
     """HBM bytes per launch of `kernel` from the newest committed counter run (profiles/*_pmc_hbm.json,
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command); None when there is none."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm.json")))
+    import re
+    # newest = highest (round, version) in the file name r<round>_v<version>_pmc_hbm.json, compared as numbers
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_v*_pmc_hbm.json")),
+                   key=lambda f: [int(x) for x in re.findall(r"\d+", os.path.basename(f))])
     if not files:
         return None
     with open(files[-1]) as f:
