@@ -12,7 +12,7 @@ def _fields(b):
     return dict(s=b[:, :7], s_=b[:, 7:14], g=b[:, 14:21], a=b[:, 21:23], r=b[:, 23:24], cr=b[:, 24:25])
 
 
-@pytest.mark.parametrize("B", [16, 32, 100, 4096])
+@pytest.mark.parametrize("B", [16, 32, 100, 4096, 32768])    # 32768: the global batch of the eight-GPU configuration on one GPU
 def test_each_step_gradients_losses_and_weights(B):
     from gpu_util import Pair, close, dev, make_batch
     p = Pair()
