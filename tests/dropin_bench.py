@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Rate of the reference's own single-transition loops (Curious_GAN.py:172-307) on the drop-in classes: every call
 hands NumPy arrays over PCIe and waits for its result, nine network executions per transition once the replay is
-full.  Beside it the same per-transition sequence on the NumPy restatement (host cores)."""
+full.  Beside it the same per-transition sequence on the NumPy restatement (host cores): that restatement is test
+infrastructure, which is why this script lives with the tests.  pytest does not collect it; run it by name."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
