@@ -53,3 +53,54 @@ def test_env_invariants_and_vector_form(seed, steps, mode):
         assert r in (0.0, 10.0) and s[0] in (0.0, 1.0)
         assert np.all(vec.theta >= 0) and np.all(vec.theta < 2 * np.pi)
         assert not done or vec.grab[0] > 50
+
+
+@settings(max_examples=25, deadline=None)
+@given(m=st.integers(2, 40), n=st.integers(1, 12), seed=st.integers(0, 2**31 - 1), shift=st.floats(-50, 50))
+def test_batchnorm_restatement_invariants(m, n, seed, shift):
+    """Training-mode batch norm (Conv_model.py:838): the output ignores a constant added to a column, has the
+    column mean beta, and its input gradient sums to zero per column (the statistics absorb the mean)."""
+    from oracle import inverse_model as om
+    rng = np.random.RandomState(seed)
+    z = rng.standard_normal((m, n)) * rng.uniform(0.5, 3, n)
+    gamma, beta = rng.uniform(0.5, 2, n), rng.uniform(-1, 1, n)
+    y, cache = om.bn_forward(z, gamma, beta, True)
+    y2, _ = om.bn_forward(z + shift, gamma, beta, True)
+    np.testing.assert_allclose(y2, y, rtol=0, atol=1e-8 * (1 + abs(shift)))
+    np.testing.assert_allclose(y.mean(0), beta, atol=1e-12)
+    dz, dg, db = om.bn_backward(rng.standard_normal((m, n)), cache)
+    np.testing.assert_allclose(dz.sum(0), 0, atol=1e-10)
+    xh, inv, _ = cache                                   # ... and is orthogonal to the normalised column up to the epsilon term
+    np.testing.assert_allclose((dz * xh).sum(0), gamma * inv * dg * (1 - (xh ** 2).mean(0)), atol=1e-9)
+
+
+@settings(max_examples=25, deadline=None)
+@given(m=st.integers(1, 30), n=st.integers(2, 14), seed=st.integers(0, 2**31 - 1), shift=st.floats(-30, 30))
+def test_softmax_cross_entropy_invariants(m, n, seed, shift):
+    """Sparse softmax cross-entropy against argmax(a) (Conv_model.py:801,818): non-negative, unchanged by a
+    constant added to a row of logits, gradient rows sum to zero, and -log(1/n) for equal logits."""
+    from oracle import inverse_model as om
+    rng = np.random.RandomState(seed)
+    logits, a = rng.standard_normal((m, n)) * 3, rng.uniform(0, 1, (m, n))
+    loss, d = om.softmax_ce(logits, a)
+    loss2, d2 = om.softmax_ce(logits + shift, a)
+    assert loss >= 0 and abs(loss - loss2) < 1e-9
+    np.testing.assert_allclose(d.sum(1), 0, atol=1e-12)
+    np.testing.assert_allclose(d2, d, atol=1e-10)
+    assert abs(om.softmax_ce(np.zeros((m, n)), a)[0] - np.log(n)) < 1e-12
+
+
+@settings(max_examples=20, deadline=None)
+@given(n=st.integers(1, 6), u=st.integers(1, 9), seed=st.integers(0, 2**31 - 1))
+def test_lstm_step_limits(n, u, seed):
+    """BasicLSTMCell (Conv_model.py:85): |h'| < 1; a saturated forget gate with a closed input gate carries the
+    cell state through unchanged."""
+    from oracle import pixel_ddpg as od
+    rng = np.random.RandomState(seed)
+    x, c, h = rng.standard_normal((n, u)), rng.standard_normal((n, u)), rng.uniform(-1, 1, (n, u))
+    kernel, bias = rng.uniform(-0.5, 0.5, (2 * u, 4 * u)), np.zeros(4 * u)
+    c2, h2 = od.lstm_step(x, c, h, kernel, bias)
+    assert np.all(np.abs(h2) < 1) and np.all(np.abs(c2) <= np.abs(c) + 1)
+    bias[:u], bias[2 * u:3 * u] = -60.0, 60.0            # i closed, f open
+    c3, _ = od.lstm_step(x, c, h, kernel * 0, bias)
+    np.testing.assert_allclose(c3, c, atol=1e-12)
