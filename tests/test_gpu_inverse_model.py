@@ -116,3 +116,29 @@ def test_batchnorm_kernels(m, n):
         close(bn.grad.cpu().numpy()[:n], dg, what="dgamma", atol=1e-5 * np.abs(d).sum(0).max())
         close(bn.grad.cpu().numpy()[n:], db, what="dbeta", atol=1e-5 * np.abs(d).sum(0).max())
         close(got.cpu().numpy(), dz, what="dz", atol=1e-5 * np.abs(dz).max())
+
+
+def test_batchnorm_properties_at_a_large_batch():
+    """65,536 rows x 500 columns, too many for the float64 restatement to be worth its time here: the output of the
+    training form has column mean beta and column deviation gamma * sqrt(var / (var + eps)), inference leaves the
+    statistics alone, and the input gradient sums to zero over every column."""
+    import rl_gan_amd as R
+    m, n = 65536, 500
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    z = torch.randn(m, n, device="cuda", generator=g) * 1.7 + 11.0
+    gamma = np.linspace(0.5, 1.5, n); beta = np.linspace(-1, 1, n)
+    bn = R.BatchNorm(n, gamma, beta)
+    y = bn.forward(z, True, False)
+    z64 = z.double()
+    var = z64.var(0, unbiased=False)
+    np.testing.assert_allclose(y.double().mean(0).cpu().numpy(), beta, atol=2e-5)
+    np.testing.assert_allclose(y.double().std(0, unbiased=False).cpu().numpy(), gamma * np.sqrt((var / (var + 1e-3)).cpu().numpy()), rtol=2e-5)
+    np.testing.assert_allclose(bn.stats[:n].cpu().numpy(), z64.mean(0).cpu().numpy(), rtol=1e-6)
+    dy = torch.randn(m, n, device="cuda", generator=g)
+    dz = bn.backward(dy, y, z, False)
+    scale = float(dz.abs().sum(0).max())
+    assert float(dz.double().sum(0).abs().max()) <= 1e-5 * scale
+    np.testing.assert_allclose(bn.grad[n:].cpu().numpy(), dy.double().sum(0).cpu().numpy(), rtol=1e-5, atol=1e-5 * float(dy.abs().sum(0).max()))
+    yi = bn.forward(z, False, False)
+    want = torch.from_numpy(gamma).cuda() * z64 / np.sqrt(1 + 1e-3) + torch.from_numpy(beta).cuda()
+    assert float((yi.double() - want).abs().max()) <= 1e-5 * float(want.abs().max())
