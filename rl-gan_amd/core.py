@@ -229,6 +229,11 @@ def launch_reduce(jobs) -> None:
     check(lib.rlgan_grad_reduce(_arr(_lib.ReduceJob, jobs), len(jobs), _stream()), "rlgan_grad_reduce")
 
 
+def row_ld(t: torch.Tensor) -> int:
+    """Leading dimension of a 2-D row tensor with unit column stride; a one-row tensor may carry any row stride."""
+    return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
+
+
 def launch_apply(jobs, reduces=None) -> None:
     """Optimizer steps; with `reduces` (one ReduceJob per apply job) the chunk reduction of the weight
     gradients runs inside the same launch."""

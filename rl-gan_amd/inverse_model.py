@@ -22,7 +22,7 @@ import torch
 
 from ._lib import check, lib
 from .conv import ConvEncoder, DenseLayer
-from .core import _stream, device
+from .core import _stream, device, row_ld
 from .pixel_gan import _adam_for, _adam_jobs
 
 N_L1, N_L2 = 500, 100                                           # Conv_model.py:832,841
@@ -132,7 +132,7 @@ class StateActionPredictor:
         if self._rows is None or self._rows.numel() < m:
             self._rows = torch.empty(m, dtype=torch.float32, device=logits.device)
         d = torch.empty_like(logits) if want_grad else None
-        check(lib.rlgan_softmax_ce(logits.data_ptr(), self.ac_pad, self.ac, a.data_ptr(), a.stride(0), m, self._rows.data_ptr(),
+        check(lib.rlgan_softmax_ce(logits.data_ptr(), self.ac_pad, self.ac, a.data_ptr(), row_ld(a), m, self._rows.data_ptr(),
                                    None if d is None else d.data_ptr(), _stream()), "rlgan_softmax_ce")
         check(lib.rlgan_sum_parts(self._rows.data_ptr(), m, 1, 1.0 / m, self.loss_out.data_ptr(), _stream()), "rlgan_sum_parts")
         return d

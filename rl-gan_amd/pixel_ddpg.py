@@ -22,7 +22,7 @@ import torch
 from . import _lib
 from ._lib import check, lib
 from .conv import ConvEncoder, DenseLayer
-from .core import _stream, device, launch_apply
+from .core import _stream, device, launch_apply, row_ld
 
 N_L1, N_L2, N_L3, L3_PAD = 200, 200, 10, 12                     # Conv_model.py:627,636,643 / :716,723,730
 
@@ -116,8 +116,8 @@ class LSTMUnit:
         """(c', h') for a batch of features and states, all on the device."""
         n = phis.shape[0]
         x = torch.empty((n, self.h_dim + self.units), dtype=torch.float32, device=phis.device)
-        check(lib.rlgan_copy_cols(phis.data_ptr(), phis.stride(0), x.data_ptr(), x.shape[1], n, self.h_dim, 0, _stream()), "rlgan_copy_cols")
-        check(lib.rlgan_copy_cols(h_in.data_ptr(), h_in.stride(0), x.data_ptr() + 4 * self.h_dim, x.shape[1], n, self.units, 0, _stream()),
+        check(lib.rlgan_copy_cols(phis.data_ptr(), row_ld(phis), x.data_ptr(), x.shape[1], n, self.h_dim, 0, _stream()), "rlgan_copy_cols")
+        check(lib.rlgan_copy_cols(h_in.data_ptr(), row_ld(h_in), x.data_ptr() + 4 * self.h_dim, x.shape[1], n, self.units, 0, _stream()),
               "rlgan_copy_cols")
         gates = self.cell.forward(x, act=False)
         c_in = c_in.contiguous()
@@ -245,8 +245,8 @@ class PixelCritic:
         """[n, k_pad] rows [phis, a, 0]; a: [n, >= a_dim], its first a_dim columns are used."""
         n = phis.shape[0]
         x = torch.empty((n, self.k_pad), dtype=torch.float32, device=phis.device)
-        check(lib.rlgan_copy_cols(phis.data_ptr(), phis.stride(0), x.data_ptr(), self.k_pad, n, self.h_dim, 0, _stream()), "rlgan_copy_cols")
-        check(lib.rlgan_copy_cols(a.data_ptr(), a.stride(0), x.data_ptr() + 4 * self.h_dim, self.k_pad, n, self.a_dim, self.a_pad - self.a_dim,
+        check(lib.rlgan_copy_cols(phis.data_ptr(), row_ld(phis), x.data_ptr(), self.k_pad, n, self.h_dim, 0, _stream()), "rlgan_copy_cols")
+        check(lib.rlgan_copy_cols(a.data_ptr(), row_ld(a), x.data_ptr() + 4 * self.h_dim, self.k_pad, n, self.a_dim, self.a_pad - self.a_dim,
                                   _stream()), "rlgan_copy_cols")
         return x
 

@@ -21,7 +21,7 @@ import torch
 from . import _lib
 from ._lib import check, lib
 from .conv import ConvEncoder, DenseLayer
-from .core import _stream, device, launch_apply
+from .core import _stream, device, launch_apply, row_ld
 from .deconv import Decoder
 
 N_L1 = 200                                                      # Conv_model.py:445
@@ -63,8 +63,12 @@ class _Adam:
 
 class PixelGenerator:
     def __init__(self, h_dim: int, a_dim: int, learning_rate: float, obs_encoder: ConvEncoder,
-                 rng: Optional[np.random.RandomState] = None, w1_s=None, w1_a=None, b1=None, decoder_params=None):
+                 rng: Optional[np.random.RandomState] = None, w1_s=None, w1_a=None, b1=None, decoder_params=None,
+                 state_encoder: Optional[ConvEncoder] = None):
+        """state_encoder: the encoder of the frame stacks, only needed by `predict` (which takes frames like the
+        reference's; the batched calls take its features)."""
         rng = rng or np.random.RandomState()
+        self.state_encoder = state_encoder
         self.h_dim, self.a_dim, self.lr = h_dim, a_dim, learning_rate
         self.k_pad = (h_dim + a_dim + 3) // 4 * 4
         if w1_s is None:                                        # xavier_initializer, biases 0.001 (Conv_model.py:439-448)
@@ -86,8 +90,8 @@ class PixelGenerator:
     def _input(self, phis: torch.Tensor, a: torch.Tensor) -> torch.Tensor:
         n = phis.shape[0]
         x = torch.empty((n, self.k_pad), dtype=torch.float32, device=phis.device)
-        check(lib.rlgan_copy_cols(phis.data_ptr(), phis.stride(0), x.data_ptr(), self.k_pad, n, self.h_dim, 0, _stream()), "rlgan_copy_cols")
-        check(lib.rlgan_copy_cols(a.data_ptr(), a.stride(0), x.data_ptr() + 4 * self.h_dim, self.k_pad, n, self.a_dim,
+        check(lib.rlgan_copy_cols(phis.data_ptr(), row_ld(phis), x.data_ptr(), self.k_pad, n, self.h_dim, 0, _stream()), "rlgan_copy_cols")
+        check(lib.rlgan_copy_cols(a.data_ptr(), row_ld(a), x.data_ptr() + 4 * self.h_dim, self.k_pad, n, self.a_dim,
                                   self.k_pad - self.h_dim - self.a_dim, _stream()), "rlgan_copy_cols")
         return x
 
@@ -97,6 +101,13 @@ class PixelGenerator:
         self._h1 = self.l1.forward(self._x, act="relu")
         self._img = self.decoder.forward(self._h1)
         return self._img
+
+    def predict(self, s, a) -> np.ndarray:
+        """The predicted next frame [42, 42, 1] for one state [h, w, c] and action (Conv_model.py:553-560)."""
+        assert self.state_encoder is not None, "predict() takes frames: construct the generator with state_encoder="
+        st = torch.as_tensor(np.asarray(s, dtype=np.float32)[None], device=device())
+        at = torch.as_tensor(np.asarray(a, dtype=np.float32)[None], device=device())
+        return self.predict_batch(self.state_encoder.forward(st), at).cpu().numpy()[0]
 
     def _pad4(self, img1: torch.Tensor) -> torch.Tensor:
         n, h, w, _ = img1.shape
@@ -220,10 +231,10 @@ class PixelDiscriminator:
         pad = self.k_pad - self.h_dim - self.obs_dim - self.a_dim
         for c in range(copies):
             base = x.data_ptr() + 4 * c * n * self.k_pad
-            check(lib.rlgan_copy_cols(phis.data_ptr(), phis.stride(0), base, self.k_pad, n, self.h_dim, 0, _stream()), "rlgan_copy_cols")
-            check(lib.rlgan_copy_cols(a.data_ptr(), a.stride(0), base + 4 * (self.h_dim + self.obs_dim), self.k_pad, n, self.a_dim, pad,
+            check(lib.rlgan_copy_cols(phis.data_ptr(), row_ld(phis), base, self.k_pad, n, self.h_dim, 0, _stream()), "rlgan_copy_cols")
+            check(lib.rlgan_copy_cols(a.data_ptr(), row_ld(a), base + 4 * (self.h_dim + self.obs_dim), self.k_pad, n, self.a_dim, pad,
                                       _stream()), "rlgan_copy_cols")
-        check(lib.rlgan_copy_cols(feats.data_ptr(), feats.stride(0), x.data_ptr() + 4 * self.h_dim, self.k_pad, copies * n, self.obs_dim, 0,
+        check(lib.rlgan_copy_cols(feats.data_ptr(), row_ld(feats), x.data_ptr() + 4 * self.h_dim, self.k_pad, copies * n, self.obs_dim, 0,
                                   _stream()), "rlgan_copy_cols")
         return x
 
@@ -240,6 +251,17 @@ class PixelDiscriminator:
         out = torch.empty((logits.shape[0], 1), dtype=torch.float32, device=logits.device)
         check(lib.rlgan_one_minus_sigmoid(logits.data_ptr(), 4, logits.shape[0], out.data_ptr(), _stream()), "rlgan_one_minus_sigmoid")
         return out
+
+    def determine(self, s, a, g) -> np.ndarray:
+        """1 - D_fake as an array of shape (1, 1) for one state [h, w, c], action and generated frame [42, 42, 1]
+        (Conv_model.py:283-294)."""
+        dev = lambda v: torch.as_tensor(np.asarray(v, dtype=np.float32)[None], device=device())
+        return self.determine_batch(dev(s), dev(a), dev(g)).cpu().numpy()
+
+    def observe_and_compare(self, s_, g) -> float:
+        """The hidden-state mode's squared feature error; 0 in 'full_prediction' mode, the one built here
+        (Conv_model.py:305-313)."""
+        return 0.
 
     def _forward_pair(self, s, a, single_s_next, g_image, phis=None):
         n = a.shape[0]

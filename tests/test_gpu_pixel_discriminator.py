@@ -111,3 +111,19 @@ def test_state_encoder_reads_the_uint8_ring():
     assert torch.equal(outs[0][0], outs[1][0])
     for x, y in zip(outs[0][1], outs[1][1]):
         assert torch.equal(x, y)
+
+
+def test_single_transition_calls_of_the_acting_loop():
+    """`generator.predict(s, a)` and `discriminator.determine(s, a, g)` as the acting loop calls them
+    (Curious_GAN_mario.py:67-71): one state in, NumPy out, equal to row 0 of the batched forms."""
+    import rl_gan_amd as R
+    D, H, T = _setup(3, 6, seed=7)
+    G = R.PixelGenerator(256, 6, 1e-4, D.obs_encoder, rng=np.random.RandomState(0), state_encoder=D.state_encoder)
+    g = G.predict(H["s"][0], H["a"][0])
+    assert g.shape == (42, 42, 1) and g.dtype == np.float32
+    want = G.predict_batch(D.state_encoder.forward(T["s"][:1]), T["a"][:1]).cpu().numpy()[0]
+    np.testing.assert_array_equal(g, want)
+    r = D.determine(H["s"][0], H["a"][0], g)
+    assert r.shape == (1, 1) and 0.0 < r[0, 0] < 1.0
+    np.testing.assert_array_equal(r, D.determine_batch(T["s"][:1], T["a"][:1], torch.from_numpy(g[None]).cuda()).cpu().numpy())
+    assert D.observe_and_compare(H["s_next"][0], g) == 0.
