@@ -42,3 +42,31 @@ class FrameMemory:
     def sample(self, n: int, rs=np.random):
         idx = rs.choice(self.len, size=n)                              # Conv_model.py:147
         return idx, np.array(self.data_s)[idx], np.array(self.data_s_)[idx]
+
+
+class PixelMemory(FrameMemory):
+    """All nine fields of `Conv_model.Memory` (Conv_model.py:102-157); `sample` returns them in the reference's order,
+    which names `b_lstm_s` twice (the stored `lstm_s_` never comes back, Conv_model.py:155-157).  Pinned by
+    tests/golden/pixel_memory_full.npz (tests/golden/gen_pixel_memory_full_fixture.py)."""
+    FIELDS = ("g", "lstm_s", "lstm_s_", "a", "dense_a", "r", "curious_r")
+
+    def __init__(self, capacity: int):
+        super().__init__(capacity)
+        self.cols = {k: [] for k in self.FIELDS}
+
+    def store_full(self, s_u8, g, lstm_s, a, r, curious_r, s_next_u8, lstm_s_, dense_a) -> None:
+        vals = dict(g=g, lstm_s=lstm_s, lstm_s_=lstm_s_, a=a, dense_a=dense_a, r=r, curious_r=curious_r)
+        if self.pointer > self.capacity:
+            i = self.pointer % self.capacity
+            for k, v in vals.items():
+                self.cols[k][i] = v
+        else:
+            for k, v in vals.items():
+                self.cols[k].append(v)
+        self.store_transition(s_u8, s_next_u8)
+
+    def sample_full(self, n: int, rs=np.random):
+        idx = rs.choice(self.len, size=n)
+        c = {k: np.array(v)[idx] for k, v in self.cols.items()}
+        lstm = np.squeeze(c["lstm_s"], 2)
+        return (np.array(self.data_s)[idx], c["g"], lstm, c["a"], c["r"], c["curious_r"], np.array(self.data_s_)[idx], lstm, c["dense_a"])

@@ -11,7 +11,7 @@ from .ddpg import Actor, Critic
 from .ddpg import Memory as DDPGMemory
 from .curious_gan import Generator, Discriminator, Memory
 from .arm_env import ArmEnv, VecArmEnv
-from .replay import DeviceMemory, FrameMemory, MT19937Device
+from .replay import DeviceMemory, FrameMemory, MT19937Device, PixelMemory
 from .engine import StepEngine, GradExchange, ActorState, CriticState, AdamState
 from .core import DeviceNet, Workspace, mlp_forward
 from .learner import CuriousLearner, LearnerConfig
@@ -23,6 +23,6 @@ from .pixel_ddpg import LSTMUnit, PixelActor, PixelCritic
 from .train import Agent, Settings, train, train_DDPG
 
 __all__ = ["Session", "placeholder", "set_random_seed", "Actor", "Critic", "Generator", "Discriminator", "Memory",
-           "DDPGMemory", "ArmEnv", "VecArmEnv", "DeviceMemory", "FrameMemory", "FrameRef", "Decoder", "DeconvLayer", "DECODER", "PixelGenerator", "PixelDiscriminator", "PixelGanTrainer", "single_frame_encoder", "StateActionPredictor", "PixelActor", "LSTMUnit", "PixelCritic", "BatchNorm", "MT19937Device", "StepEngine", "GradExchange",
+           "DDPGMemory", "ArmEnv", "VecArmEnv", "DeviceMemory", "FrameMemory", "PixelMemory", "FrameRef", "Decoder", "DeconvLayer", "DECODER", "PixelGenerator", "PixelDiscriminator", "PixelGanTrainer", "single_frame_encoder", "StateActionPredictor", "PixelActor", "LSTMUnit", "PixelCritic", "BatchNorm", "MT19937Device", "StepEngine", "GradExchange",
            "CuriousLearner", "LearnerConfig", "DeviceNet", "mlp_forward", "ConvEncoder", "ConvLayer", "DenseLayer", "DOOM_HEAD",
            "universe_head", "Agent", "Settings", "train", "train_DDPG"]

@@ -212,3 +212,84 @@ class FrameMemory:
         """(indices, b_s, b_s_) on the device: Conv_model.py:145-157 for the two image fields."""
         idx = self.sample_indices(n)
         return idx, self.gather(idx, "s"), self.gather(idx, "s_")
+
+
+class PixelMemory:
+    """`Conv_model.Memory` (Conv_model.py:102-157) with all nine fields of a transition, as the pixel training loop
+    fills and reads it (Curious_GAN_mario.py:75,86): the frame stacks s and s' in a uint8 `FrameMemory`, everything
+    else in one float32 ring with the same slots, row = [g | lstm_s (c, h) | lstm_s_ | a | dense_a | r | curious_r].
+
+    Frames may be handed over as uint8 or as the wrapper's float32 `uint8 * 1/255` (env_wrapper.py:44,58), which is
+    turned back into the bytes it came from; anything else is refused, because it could not be restored bit for bit.
+    `sample` returns the reference's nine arrays in its order, `b_lstm_s` twice like the reference
+    (Conv_model.py:155-157); the action comes back as float32 (the reference hands back the integer one-hot rows it
+    was given, which every consumer feeds to a float32 placeholder)."""
+
+    def __init__(self, capacity: int, shape=(42, 42, 4), a_dim: int = 6, lstm_units: int = 256, g_shape=None,
+                 rng: Optional[MT19937Device] = None):
+        self.frames = FrameMemory(capacity, shape, rng=rng)
+        self.capacity, self.shape, self.a_dim, self.units = int(capacity), tuple(shape), int(a_dim), int(lstm_units)
+        self.g_shape = tuple(g_shape) if g_shape is not None else (self.shape[0], self.shape[1], 1)
+        ng, nl = int(np.prod(self.g_shape)), 2 * self.units
+        self.off = dict(g=0, lstm_s=ng, lstm_s_=ng + nl, a=ng + 2 * nl, dense_a=ng + 2 * nl + self.a_dim)
+        self.off["r"] = self.off["dense_a"] + 1
+        self.off["curious_r"] = self.off["r"] + 1
+        self.dims = self.off["curious_r"] + 1
+        self.ld = (self.dims + 31) // 32 * 32
+        self.slots = self.capacity + 1
+        self._rows = torch.zeros((self.slots, self.ld), dtype=torch.float32, device=device())
+        self._stage = torch.zeros((1, self.ld), dtype=torch.float32, device=device())
+
+    pointer = property(lambda self: self.frames.pointer)
+    len = property(lambda self: self.frames.len)
+
+    @staticmethod
+    def _bytes(f) -> np.ndarray:
+        f = np.asarray(f)
+        if f.dtype == np.uint8:
+            return f
+        u8 = np.rint(f.astype(np.float64) * 255.0).astype(np.uint8)
+        if not np.array_equal(u8.astype(np.float32) * FrameMemory.SCALE, f.astype(np.float32)):
+            raise ValueError("frame stacks must be uint8 or uint8 * (1/255) as float32 (env_wrapper.py:44,58)")
+        return u8
+
+    def store_transition(self, s, g, lstm_s, a, r, curious_r, s_, lstm_s_, dense_a) -> None:
+        """Conv_model.py:116-143."""
+        p = self.frames.pointer
+        slot = p % self.capacity if p > self.capacity else p
+        row = np.zeros(self.ld, dtype=np.float32)
+        o = self.off
+        row[o["g"]:o["lstm_s"]] = np.asarray(g, dtype=np.float32).reshape(-1)
+        row[o["lstm_s"]:o["lstm_s_"]] = np.asarray(lstm_s, dtype=np.float32).reshape(-1)
+        row[o["lstm_s_"]:o["a"]] = np.asarray(lstm_s_, dtype=np.float32).reshape(-1)
+        row[o["a"]:o["dense_a"]] = np.asarray(a, dtype=np.float32).reshape(-1)
+        row[o["dense_a"]], row[o["r"]] = float(np.ravel(dense_a)[0]), float(np.ravel(r)[0])
+        row[o["curious_r"]] = float(np.ravel(curious_r)[0])
+        self._stage.copy_(torch.from_numpy(row)[None])
+        # the float ring has capacity + 1 slots; with that as the ring size the store's `% size` leaves the slot alone
+        check(lib.rlgan_replay_store(self._rows.data_ptr(), self.slots, self.dims, self.ld, slot, self._stage.data_ptr(), self.ld, 1,
+                                     _stream()), "rlgan_replay_store")
+        self.frames.store_transition(self._bytes(s), self._bytes(s_))
+
+    def sample_device(self, n: int) -> dict:
+        """The minibatch on the device: idx, s, s_ (float32 frames) and the float fields as column views of one
+        gathered [n, dims] tensor."""
+        idx = self.frames.sample_indices(n)
+        rows = torch.empty((n, self.dims), dtype=torch.float32, device=self._rows.device)
+        check(lib.rlgan_replay_gather(self._rows.data_ptr(), self.slots, self.dims, self.ld, idx.data_ptr(), n, rows.data_ptr(),
+                                      rows.stride(0), _stream()), "rlgan_replay_gather")
+        o = self.off
+        cut = lambda a, b: rows[:, o[a]:(o[b] if b else self.dims)]
+        return dict(idx=idx, rows=rows, s=self.frames.gather(idx, "s"), s_=self.frames.gather(idx, "s_"), g=cut("g", "lstm_s"),
+                    lstm_s=cut("lstm_s", "lstm_s_"), lstm_s_=cut("lstm_s_", "a"), a=cut("a", "dense_a"), dense_a=cut("dense_a", "r"),
+                    r=cut("r", "curious_r"), curious_r=cut("curious_r", None))
+
+    def sample(self, n: int):
+        """Conv_model.py:145-157: (b_s, b_g, b_lstm_s, b_a, b_r, b_curious_r, b_s_, b_lstm_s, b_d_a) as NumPy arrays."""
+        d = self.sample_device(n)
+        rows = d["rows"].cpu().numpy()
+        o = self.off
+        b_g = rows[:, o["g"]:o["lstm_s"]].reshape((n,) + self.g_shape)
+        b_lstm = rows[:, o["lstm_s"]:o["lstm_s_"]].reshape(n, 2, self.units)
+        return (d["s"].cpu().numpy(), b_g, b_lstm, rows[:, o["a"]:o["dense_a"]], rows[:, o["r"]].astype(np.float64),
+                rows[:, o["curious_r"]:o["curious_r"] + 1], d["s_"].cpu().numpy(), b_lstm, rows[:, o["dense_a"]])

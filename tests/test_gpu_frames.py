@@ -169,3 +169,34 @@ def test_u8_conv_argument_errors():
     assert lib.rlgan_conv_forward_u8(L.conv, r + 2, 4, None, 1.0, w, yo, 2, 1, None) == E_ALIGN
     assert lib.rlgan_conv_backward_weights_u8(L.conv, r, 4, None, 1.0, None, None, yo, 4, L.grad.data_ptr(), 2, None) == E_ARG
     torch.cuda.synchronize()
+
+
+def test_pixel_memory_returns_what_the_reference_memory_returned():
+    """All nine fields through the device replay against the arrays the reference's own `Conv_model.Memory.sample`
+    produced for the same stores and NumPy seed (tests/golden/pixel_memory_full.npz): bit for bit, float frames
+    accepted as uint8 * 1/255, the index draw taken from NumPy's global stream like the reference's."""
+    import os
+    import rl_gan_amd as R
+    F = np.load(os.path.join(os.path.dirname(__file__), "golden", "pixel_memory_full.npz"))
+    M = R.PixelMemory(int(F["capacity"]), shape=F["frames_s"].shape[1:], a_dim=int(F["ac"]), lstm_units=int(F["units"]))
+    for i in range(F["frames_s"].shape[0]):
+        s = F["frames_s"][i].astype(np.float32) * (1.0 / 255)              # env_wrapper.py:58
+        s_ = F["frames_s_"][i] if i % 2 else F["frames_s_"][i].astype(np.float32) * (1.0 / 255)
+        M.store_transition(s, F["g"][i], [F["lstm_s"][i, 0], F["lstm_s"][i, 1]], F["a"][i], float(F["r"][i]), F["curious_r"][i], s_,
+                           [F["lstm_s_"][i, 0], F["lstm_s_"][i, 1]], int(F["dense_a"][i]))
+    assert M.pointer == int(F["pointer"]) and M.len == int(F["len"])
+    np.random.seed(int(F["sample_seed"]))
+    out = M.sample(10)
+    after = np.random.random()
+    np.random.seed(int(F["sample_seed"])); np.random.choice(M.len, size=10)
+    assert after == np.random.random()                                     # the global stream moved exactly like the reference's
+    names = ("b_s", "b_g", "b_lstm_s", "b_a", "b_r", "b_curious_r", "b_s_", "b_lstm_s_again", "b_d_a")
+    assert len(out) == 9
+    for k, v in zip(names, out):
+        assert np.asarray(v).shape == F[k].shape, k
+        np.testing.assert_array_equal(np.asarray(v, dtype=np.float64), F[k].astype(np.float64), err_msg=k)
+    d = M.sample_device(4)
+    assert d["s"].shape == (4,) + F["frames_s"].shape[1:] and d["curious_r"].shape == (4, 1) and d["a"].shape == (4, int(F["ac"]))
+    with pytest.raises(ValueError):
+        M.store_transition(np.full(F["frames_s"].shape[1:], 0.3, np.float32), F["g"][0], [F["lstm_s"][0, 0], F["lstm_s"][0, 1]], F["a"][0],
+                           0.0, F["curious_r"][0], F["frames_s_"][0], [F["lstm_s_"][0, 0], F["lstm_s_"][0, 1]], 0)

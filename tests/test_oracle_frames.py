@@ -45,3 +45,20 @@ def test_sample_draws_the_reference_indices_and_frames():
 def test_slot_rule():
     m = OF.FrameMemory(5)
     assert [m.slot_of(p) for p in range(13)] == [0, 1, 2, 3, 4, 5, 1, 2, 3, 4, 0, 1, 2]
+
+
+def test_all_nine_fields_against_the_reference_made_fixture():
+    """oracle.frames.PixelMemory against what the reference's own `Conv_model.Memory` returned for the same stores
+    and the same NumPy seed (tests/golden/pixel_memory_full.npz)."""
+    import os
+    from oracle.frames import PixelMemory
+    F = np.load(os.path.join(os.path.dirname(__file__), "golden", "pixel_memory_full.npz"))
+    M = PixelMemory(int(F["capacity"]))
+    for i in range(F["frames_s"].shape[0]):
+        M.store_full(F["frames_s"][i], F["g"][i], [F["lstm_s"][i, 0], F["lstm_s"][i, 1]], F["a"][i], float(F["r"][i]), F["curious_r"][i],
+                     F["frames_s_"][i], [F["lstm_s_"][i, 0], F["lstm_s_"][i, 1]], int(F["dense_a"][i]))
+    assert M.pointer == int(F["pointer"]) and M.len == int(F["len"])
+    out = M.sample_full(10, np.random.RandomState(int(F["sample_seed"])))
+    names = ("b_s", "b_g", "b_lstm_s", "b_a", "b_r", "b_curious_r", "b_s_", "b_lstm_s_again", "b_d_a")
+    for k, v in zip(names, out):
+        np.testing.assert_array_equal(np.asarray(v), F[k], err_msg=k)
