@@ -20,9 +20,10 @@ from .deconv import Decoder, DeconvLayer, DECODER
 from .pixel_gan import PixelDiscriminator, PixelGanTrainer, PixelGenerator, single_frame_encoder
 from .inverse_model import BatchNorm, StateActionPredictor
 from .pixel_ddpg import LSTMUnit, PixelActor, PixelCritic
+from .train_pixel import PixelAgent, PixelSettings, train_pixel, transfer_sparse_action
 from .train import Agent, Settings, train, train_DDPG
 
 __all__ = ["Session", "placeholder", "set_random_seed", "Actor", "Critic", "Generator", "Discriminator", "Memory",
-           "DDPGMemory", "ArmEnv", "VecArmEnv", "DeviceMemory", "FrameMemory", "PixelMemory", "FrameRef", "Decoder", "DeconvLayer", "DECODER", "PixelGenerator", "PixelDiscriminator", "PixelGanTrainer", "single_frame_encoder", "StateActionPredictor", "PixelActor", "LSTMUnit", "PixelCritic", "BatchNorm", "MT19937Device", "StepEngine", "GradExchange",
+           "DDPGMemory", "ArmEnv", "VecArmEnv", "DeviceMemory", "FrameMemory", "PixelMemory", "PixelAgent", "PixelSettings", "train_pixel", "transfer_sparse_action", "FrameRef", "Decoder", "DeconvLayer", "DECODER", "PixelGenerator", "PixelDiscriminator", "PixelGanTrainer", "single_frame_encoder", "StateActionPredictor", "PixelActor", "LSTMUnit", "PixelCritic", "BatchNorm", "MT19937Device", "StepEngine", "GradExchange",
            "CuriousLearner", "LearnerConfig", "DeviceNet", "mlp_forward", "ConvEncoder", "ConvLayer", "DenseLayer", "DOOM_HEAD",
            "universe_head", "Agent", "Settings", "train", "train_DDPG"]

@@ -226,13 +226,16 @@ class PixelMemory:
     was given, which every consumer feeds to a float32 placeholder)."""
 
     def __init__(self, capacity: int, shape=(42, 42, 4), a_dim: int = 6, lstm_units: int = 256, g_shape=None,
-                 rng: Optional[MT19937Device] = None):
+                 rng: Optional[MT19937Device] = None, dense_dim: Optional[int] = None):
+        """dense_dim: width of the `dense_a` field; the training loop stores `transfer_sparse_action(a)`, a vector as
+        long as the action (Curious_GAN_mario.py:64,267-270), which is the default; 1 for a scalar."""
         self.frames = FrameMemory(capacity, shape, rng=rng)
         self.capacity, self.shape, self.a_dim, self.units = int(capacity), tuple(shape), int(a_dim), int(lstm_units)
         self.g_shape = tuple(g_shape) if g_shape is not None else (self.shape[0], self.shape[1], 1)
         ng, nl = int(np.prod(self.g_shape)), 2 * self.units
         self.off = dict(g=0, lstm_s=ng, lstm_s_=ng + nl, a=ng + 2 * nl, dense_a=ng + 2 * nl + self.a_dim)
-        self.off["r"] = self.off["dense_a"] + 1
+        self.dense_dim = self.a_dim if dense_dim is None else int(dense_dim)
+        self.off["r"] = self.off["dense_a"] + self.dense_dim
         self.off["curious_r"] = self.off["r"] + 1
         self.dims = self.off["curious_r"] + 1
         self.ld = (self.dims + 31) // 32 * 32
@@ -263,7 +266,8 @@ class PixelMemory:
         row[o["lstm_s"]:o["lstm_s_"]] = np.asarray(lstm_s, dtype=np.float32).reshape(-1)
         row[o["lstm_s_"]:o["a"]] = np.asarray(lstm_s_, dtype=np.float32).reshape(-1)
         row[o["a"]:o["dense_a"]] = np.asarray(a, dtype=np.float32).reshape(-1)
-        row[o["dense_a"]], row[o["r"]] = float(np.ravel(dense_a)[0]), float(np.ravel(r)[0])
+        row[o["dense_a"]:o["r"]] = np.asarray(dense_a, dtype=np.float32).reshape(-1)
+        row[o["r"]] = float(np.ravel(r)[0])
         row[o["curious_r"]] = float(np.ravel(curious_r)[0])
         self._stage.copy_(torch.from_numpy(row)[None])
         # the float ring has capacity + 1 slots; with that as the ring size the store's `% size` leaves the slot alone
@@ -292,4 +296,5 @@ class PixelMemory:
         b_g = rows[:, o["g"]:o["lstm_s"]].reshape((n,) + self.g_shape)
         b_lstm = rows[:, o["lstm_s"]:o["lstm_s_"]].reshape(n, 2, self.units)
         return (d["s"].cpu().numpy(), b_g, b_lstm, rows[:, o["a"]:o["dense_a"]], rows[:, o["r"]].astype(np.float64),
-                rows[:, o["curious_r"]:o["curious_r"] + 1], d["s_"].cpu().numpy(), b_lstm, rows[:, o["dense_a"]])
+                rows[:, o["curious_r"]:o["curious_r"] + 1], d["s_"].cpu().numpy(), b_lstm,
+                rows[:, o["dense_a"]] if self.dense_dim == 1 else rows[:, o["dense_a"]:o["r"]])

@@ -178,7 +178,7 @@ def test_pixel_memory_returns_what_the_reference_memory_returned():
     import os
     import rl_gan_amd as R
     F = np.load(os.path.join(os.path.dirname(__file__), "golden", "pixel_memory_full.npz"))
-    M = R.PixelMemory(int(F["capacity"]), shape=F["frames_s"].shape[1:], a_dim=int(F["ac"]), lstm_units=int(F["units"]))
+    M = R.PixelMemory(int(F["capacity"]), shape=F["frames_s"].shape[1:], a_dim=int(F["ac"]), lstm_units=int(F["units"]), dense_dim=1)
     for i in range(F["frames_s"].shape[0]):
         s = F["frames_s"][i].astype(np.float32) * (1.0 / 255)              # env_wrapper.py:58
         s_ = F["frames_s_"][i] if i % 2 else F["frames_s_"][i].astype(np.float32) * (1.0 / 255)
@@ -195,6 +195,12 @@ def test_pixel_memory_returns_what_the_reference_memory_returned():
     for k, v in zip(names, out):
         assert np.asarray(v).shape == F[k].shape, k
         np.testing.assert_array_equal(np.asarray(v, dtype=np.float64), F[k].astype(np.float64), err_msg=k)
+    # the training loop's dense action is a vector as long as the action (Curious_GAN_mario.py:267-270)
+    M2 = R.PixelMemory(3, shape=F["frames_s"].shape[1:], a_dim=int(F["ac"]), lstm_units=int(F["units"]))
+    dense = np.ones(int(F["ac"])) * 0.1; dense[1] = 1
+    M2.store_transition(F["frames_s"][0], F["g"][0], [F["lstm_s"][0, 0], F["lstm_s"][0, 1]], F["a"][0], 1.0, F["curious_r"][0], F["frames_s_"][0],
+                        [F["lstm_s_"][0, 0], F["lstm_s_"][0, 1]], dense)
+    np.testing.assert_array_equal(M2.sample(2)[8], np.tile(dense.astype(np.float32), (2, 1)))
     d = M.sample_device(4)
     assert d["s"].shape == (4,) + F["frames_s"].shape[1:] and d["curious_r"].shape == (4, 1) and d["a"].shape == (4, int(F["ac"]))
     with pytest.raises(ValueError):

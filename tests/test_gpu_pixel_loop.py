@@ -1,0 +1,64 @@
+"""The pixel variant's training loop (Curious_GAN_mario.py:19-165) on the device classes, driven by a small synthetic
+environment with the wrapper's interface (gym and the emulator are not available): bookkeeping of the reference
+(replay gate, episode ends, exploration decay, learning-rate steps) and run-to-run determinism."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+class ToyEnv:
+    """Frame stacks of random bytes scaled by 1/255 (env_wrapper.py:44,58); reward 1 when the first action is taken."""
+
+    def __init__(self, seed, shape=(42, 42, 4), life_ends_at=None):
+        self.rng, self.shape, self.t, self.life_ends_at = np.random.RandomState(seed), shape, 0, life_ends_at
+
+    def _frames(self):
+        return self.rng.randint(0, 256, self.shape).astype(np.uint8).astype(np.float32) * (1.0 / 255)
+
+    def reset(self):
+        self.t = 0
+        return self._frames()
+
+    def _step(self, a):
+        self.t += 1
+        life = 0 if self.life_ends_at is not None and self.t >= self.life_ends_at else 1
+        return self._frames(), float(np.argmax(a) == 0), False, {"life": life, "time": 400 - self.t}, None
+
+
+def _run(seed=1):
+    import rl_gan_amd as R
+    np.random.seed(seed)
+    cfg = R.PixelSettings(MEMORY_CAPACITY=12, BATCH_SIZE=8, MAX_EP_STEPS=10, LR_DECAY_LIST=[20, 25], SEED=seed)
+    agent = R.PixelAgent(cfg)
+    envs = iter(range(100))
+    hist = R.train_pixel(agent, lambda: ToyEnv(next(envs), life_ends_at=7 if agent.total_steps >= 20 else None), episodes=3, log=None)
+    return agent, hist
+
+
+def test_loop_bookkeeping_and_determinism():
+    agent, hist = _run()
+    # episodes 0 and 1 run their 10 steps; episode 2 ends when the toy environment reports life == 0 at its step 7
+    assert [h["steps"] for h in hist] == [10, 10, 7]
+    assert agent.M.pointer == 27 and agent.total_steps == 27 and agent.M.len == 13
+    np.testing.assert_allclose([h["Explore"] for h in hist], [2 * .99, 2 * .99 ** 2, 2 * .99 ** 3])
+    learned = 27 - 12                                       # every transition from the 13th on (pointer > MEMORY_CAPACITY after its store)
+    for counter in (agent.generator.step, agent.discriminator.step, agent.A_pred.step, agent.critic.t_replace_counter,
+                    agent.actor.t_replace_counter):
+        assert int(counter.item()) == learned
+    assert agent.lr_pointer == 2                            # total_steps passed 20 and 25
+    for h in hist[1:]:
+        assert np.isfinite([h["D_loss"], h["G_loss"], h["A_pred_loss"], h["Curious_R"]]).all() and h["D_loss"] > 0
+    assert hist[0]["D_loss"] == 0 and hist[2]["Prediction_error"] == 0
+    again, hist2 = _run()
+    assert hist == hist2
+    for a, b in zip(agent.generator._opt + agent.discriminator._opt + agent.A_pred._opt, again.generator._opt + again.discriminator._opt + again.A_pred._opt):
+        assert torch.equal(a.layer.canon, b.layer.canon)
+    for a, b in zip(agent.actor._opt + agent.critic._opt, again.actor._opt + again.critic._opt):
+        assert torch.equal(a.layer.canon, b.layer.canon) and torch.equal(a.target.canon, b.target.canon)
+
+
+def test_transfer_sparse_action():
+    import rl_gan_amd as R
+    np.testing.assert_array_equal(R.transfer_sparse_action(np.array([0, 0, 1, 0])), [0.1, 0.1, 1.0, 0.1])
