@@ -597,7 +597,14 @@ __global__ __launch_bounds__(256) void apply_kernel(const ApplyArgs A) {
   } else {
     // tf.train.AdamOptimizer: lr_t = lr*sqrt(1-b2^t)/(1-b1^t); w <- w - lr_t*m/(sqrt(v)+eps)
     const int t = t_adam;
-    const float lr_t = (float)(J.lr * sqrt(1.0 - pow(J.beta2, (double)t)) / (1.0 - pow(J.beta1, (double)t)));
+    // beta^t by repeated squaring (t is an integer and the same for the whole launch: a scalar loop of at most 31 steps,
+    // far shorter than the general pow(); relative error of a few 2^-53)
+    double p1 = 1.0, p2 = 1.0, b1 = J.beta1, b2 = J.beta2;
+    for (int e = t; e > 0; e >>= 1) {
+      if (e & 1) { p1 *= b1; p2 *= b2; }
+      b1 *= b1; b2 *= b2;
+    }
+    const float lr_t = (float)(J.lr * sqrt(1.0 - p2) / (1.0 - p1));
     const float fb1 = (float)J.beta1, fb2 = (float)J.beta2;
     const float m = fb1 * s0_old + (1.f - fb1) * g;
     const float v = fb2 * s1_old + (1.f - fb2) * g * g;
