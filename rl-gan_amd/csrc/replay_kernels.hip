@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void frames_store_kernel(uint32_t* __restrict_
     for (int j = 0; j < 4; ++j) v[j] = w0 + j * 256 < words ? src[w0 + j * 256] : 0u;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      if (w0 + j * 256 < words) dst[w0 + j * 256] = v[j];
+      if (w0 + j * 256 < words) __builtin_nontemporal_store(v[j], &dst[w0 + j * 256]);   // written once, read much later
   }
 }
 
@@ -110,8 +110,8 @@ __global__ __launch_bounds__(256) void frames_gather_kernel(const uint32_t* __re
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       if (w0 + j * 256 < words)
-        dst[w0 + j * 256] = f32x4{(float)(v[j] & 255u) * scale, (float)((v[j] >> 8) & 255u) * scale,
-                                  (float)((v[j] >> 16) & 255u) * scale, (float)(v[j] >> 24) * scale};
+        __builtin_nontemporal_store(f32x4{(float)(v[j] & 255u) * scale, (float)((v[j] >> 8) & 255u) * scale,
+                                          (float)((v[j] >> 16) & 255u) * scale, (float)(v[j] >> 24) * scale}, &dst[w0 + j * 256]);
   }
 }
 
