@@ -364,7 +364,7 @@ class StepEngine:
         the reduction runs inside the optimizer launch."""
         if self.exchange.enabled:
             launch_reduce(reduce_jobs)
-            self.exchange.all_reduce_sum(bucket)
+            self._timed(f"exchange_{bucket.numel() * 4 // 1024}KiB", lambda: self.exchange.all_reduce_sum(bucket))
             launch_apply(apply_jobs)
         else:
             launch_apply(apply_jobs, reduce_jobs)
