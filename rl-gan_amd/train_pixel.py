@@ -77,6 +77,64 @@ class PixelAgent:
         self.total_steps = 0
         self.lr_pointer = 0
 
+    # ---- checkpoints ---------------------------------------------------------------------------------
+    def _state_tensors(self) -> dict:
+        """Every device tensor that defines the training state, under a stable name: the parameters of each layer in
+        the layout the layer keeps them in (kernel then bias, widths padded as the classes document), the optimizer
+        slots of each optimizer (the encoders appear once as parameters and once per optimizer that trains them, like
+        TensorFlow's slot variables), the step and target-replacement counters."""
+        out = {}
+        for name, enc in (("feature_abstraction", self.state_encoder), ("single_feature_abstraction", self.obs_encoder)):
+            for i, L in enumerate(enc.layers + [enc.head]):
+                out[f"{name}/{i}"] = L.canon
+        nets = dict(A_pred=self.A_pred, Generator=self.generator, Discriminator=self.discriminator)
+        for name, net in nets.items():
+            for i, o in enumerate(net._opt):
+                own = not any(o.layer is L for enc in (self.state_encoder, self.obs_encoder) for L in enc.layers + [enc.head])
+                if own:
+                    out[f"{name}/{i}"] = o.layer.canon
+                out[f"{name}/Adam/{i}/m"], out[f"{name}/Adam/{i}/v"] = o.m, o.v
+            out[f"{name}/step"] = net.step
+        for name, net in (("Actor", self.actor), ("Critic", self.critic)):
+            for i, o in enumerate(net._opt):
+                out[f"{name}/eval_net/{i}"], out[f"{name}/target_net/{i}"] = o.layer.canon, o.target.canon
+                out[f"{name}/RMSProp/{i}"] = o.ms
+            out[f"{name}/t_replace_counter"] = net.t_replace_counter
+        for name, unit in (("Actor/eval_net/lstm", self.actor.LSTM_unit), ("Actor/target_net/lstm", self.actor.LSTM_unit_)):
+            out[name] = unit.cell.canon
+        return out
+
+    def save_checkpoint(self, path: str) -> None:
+        """What the reference's Saver keeps (Curious_GAN_mario.py:167-172) plus what it leaves out and a bit-exact
+        continuation needs: optimizer slots, counters, the exploration scale, the learning-rate pointer and NumPy's
+        stream.  The replay is not saved, like the reference's."""
+        st = np.random.get_state()
+        np.savez(path, **{k: v.cpu().numpy() for k, v in self._state_tensors().items()},
+                 **{"host/var": self.var, "host/total_steps": self.total_steps, "host/lr_pointer": self.lr_pointer,
+                    "host/np_keys": st[1], "host/np_pos": st[2], "host/np_gauss": np.array([st[3], st[4]])})
+
+    def load_checkpoint(self, path: str) -> None:
+        with np.load(path) as f:
+            tensors = self._state_tensors()
+            missing = [k for k in tensors if k not in f.files]
+            if missing:
+                raise KeyError(f"checkpoint lacks {missing[:3]}...")
+            for k, t in tensors.items():
+                a = f[k]
+                if a.shape != tuple(t.shape):
+                    raise ValueError(f"{k}: checkpoint has shape {a.shape}, the model {tuple(t.shape)}")
+                t.copy_(torch.from_numpy(a))
+            self.var, self.total_steps = float(f["host/var"]), int(f["host/total_steps"])
+            self.lr_pointer = int(f["host/lr_pointer"])
+            g = f["host/np_gauss"]
+            np.random.set_state(("MT19937", f["host/np_keys"], int(f["host/np_pos"]), int(g[0]), float(g[1])))
+        # the convolutions and the decoder keep fragment images of their parameters: rebuild them from the loaded values
+        for enc in (self.state_encoder, self.obs_encoder):
+            for L in enc.layers:
+                L.pack()
+        for L in self.generator.decoder.layers:
+            L.pack()
+
     def learn_minibatch(self) -> dict:
         """Curious_GAN_mario.py:82-103 on one sampled minibatch; returns the three evaluated losses."""
         cfg, G, D = self.cfg, self.generator, self.discriminator

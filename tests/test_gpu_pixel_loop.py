@@ -62,3 +62,24 @@ def test_loop_bookkeeping_and_determinism():
 def test_transfer_sparse_action():
     import rl_gan_amd as R
     np.testing.assert_array_equal(R.transfer_sparse_action(np.array([0, 0, 1, 0])), [0.1, 0.1, 1.0, 0.1])
+
+
+def test_checkpoint_continues_bit_for_bit(tmp_path):
+    """A second agent restored from a checkpoint learns exactly like the one that kept going: weights, both kinds of
+    optimizer slots, counters, exploration scale, learning-rate pointer and NumPy's stream are all in the file."""
+    import rl_gan_amd as R
+    agent, _ = _run(seed=4)
+    path = str(tmp_path / "pixel.npz")
+    agent.save_checkpoint(path)
+    other = R.PixelAgent(R.PixelSettings(MEMORY_CAPACITY=12, BATCH_SIZE=8, MAX_EP_STEPS=10, LR_DECAY_LIST=[20, 25], SEED=99))
+    np.random.seed(123)
+    other.load_checkpoint(path)
+    assert other.var == agent.var and other.total_steps == agent.total_steps and other.lr_pointer == agent.lr_pointer
+    other.M = agent.M                                       # the replay is not part of the checkpoint (nor of the reference's)
+    st = np.random.get_state()
+    la = [agent.learn_minibatch() for _ in range(3)]
+    np.random.set_state(st)                                 # the same index draws for the restored agent
+    agent2_losses = [other.learn_minibatch() for _ in range(3)]
+    assert la == agent2_losses
+    for (ka, ta), (kb, tb) in zip(agent._state_tensors().items(), other._state_tensors().items()):
+        assert ka == kb and torch.equal(ta, tb), ka
