@@ -41,9 +41,34 @@ class GradExchange:
         self.group = group
         self.world = dist.get_world_size(group) if self.enabled else 1
         self.rank = dist.get_rank(group) if self.enabled else 0
+        # RLGAN_EXCHANGE=symm (opt-in): buckets live in PyTorch's symmetric memory and are summed by its one-shot
+        # all-reduce (every rank reads every peer's bucket over xGMI and adds them in rank order) instead of RCCL's
+        # all-reduce: one kernel, no ring, for messages this small.  Off by default: it has only been exercised with one
+        # rank (symmetric memory refuses ranks that share a GPU, so a one-GPU box cannot rehearse more).
+        self.symm = self.enabled and os.environ.get("RLGAN_EXCHANGE", "rccl") == "symm"
+        self._symm_out = {}
+
+    def new_bucket(self, n: int) -> torch.Tensor:
+        """A zeroed flat fp32 bucket of n floats for `all_reduce_sum`."""
+        b = torch.zeros(n, dtype=torch.float32, device=device())
+        if self.symm:
+            import torch.distributed._symmetric_memory as sm
+            grp = self.group if self.group is not None else self.dist.group.WORLD
+            stage = sm.empty(n, dtype=torch.float32, device=device())     # what the peers read; `b` receives the sum
+            sm.rendezvous(stage, grp.group_name)
+            self._symm_out[b.data_ptr()] = (grp.group_name, stage)
+        return b
 
     def all_reduce_sum(self, bucket: torch.Tensor) -> None:
         if not self.enabled:
+            return
+        if self.symm and bucket.data_ptr() in self._symm_out:
+            # The stage is written again only two exchanges later (the two phases have a bucket each), and a rank gets
+            # past the entry barrier of the exchange in between only once every peer has left this one: no peer can
+            # still be reading the stage then.
+            name, stage = self._symm_out[bucket.data_ptr()]
+            stage.copy_(bucket)
+            torch.ops.symm_mem.one_shot_all_reduce_out(stage, "sum", name, bucket)
             return
         if bucket.is_cuda and self.dist.get_backend(self.group) == "gloo":
             # test rigs only (several ranks on one GPU): gloo moves the bucket through host memory
@@ -151,7 +176,7 @@ class StepEngine:
         return self._get(("lp", tag, n), lambda: torch.zeros(n, dtype=torch.float32, device=device()))
 
     def bucket(self, tag: str, n: int) -> torch.Tensor:
-        return self._get(("bucket", tag, n), lambda: torch.zeros(n, dtype=torch.float32, device=device()))
+        return self._get(("bucket", tag, n), lambda: self.exchange.new_bucket(n))
 
     def _inv_gb(self, n_rows: int) -> float:
         return 1.0 / float(n_rows * self.exchange.world)
