@@ -142,6 +142,10 @@ class StepEngine:
         self._ws: Dict[Tuple, object] = {}
         self.losses = torch.zeros(8, dtype=torch.float32, device=device())
         self.kernel_events = None     # set to {} to record (start, end) event pairs per kernel launch
+        # RLGAN_CHAINS=2 (opt-in, only with more than one rank): the update runs as two chains on two streams, critic
+        # step -> actor step and D step -> G step, each step with its own exchange, so that one chain computes while the
+        # other waits for its all-reduce.  On one GPU the two fused phase launches are faster (nothing to wait for).
+        self.two_chains = os.environ.get("RLGAN_CHAINS") == "2"
 
     def _timed(self, name: str, launch):
         """Run `launch()`; when kernel_events is a dict, bracket it with events on the launch stream."""
@@ -356,6 +360,11 @@ class StepEngine:
         b_a = batch[:, 3 * S:3 * S + Ad]
         b_r = batch[:, 3 * S + Ad + (1 if use_curious_reward else 0)]
         nc, na, nd, ng = C.e.n_params, A.e.n_params, D.net.n_params, G.net.n_params
+        if self.two_chains and self.exchange.enabled:
+            self._update_two_chains(A, C, G, D, b_s, b_a, b_r, b_s_, b_g, smooth, idx, n)
+            if with_eval:
+                self.gan_eval(G, D, b_g, b_s_, b_s, b_a, smooth, idx)
+            return
         # phase 1: critic step and discriminator step, tile by tile in one launch
         cargs, wc, wa, lpc = self._critic_args(C, A, b_s, b_a, b_r, b_s_, idx)
         dargs, wd, lpd = self._disc_args(D, b_g, b_s_, b_s, b_a, smooth, idx)
@@ -383,6 +392,45 @@ class StepEngine:
             [self._actor_apply_job(A, wa2), adam_job(G.net, wg.grad, G.m, G.v, G.step, G.lr)])
         if with_eval:
             self.gan_eval(G, D, b_g, b_s_, b_s, b_a, smooth, idx)
+
+    def _update_two_chains(self, A, C, G, D, b_s, b_a, b_r, b_s_, b_g, smooth, idx, n) -> None:
+        """The same four steps as two chains on two streams (the DDPG nets and the GAN nets share nothing inside an
+        update).  The steps are issued in the order their gradients become ready -- D, critic, G, actor -- because the
+        collectives of one process group run one after the other in issue order."""
+        S, Ad = self.s_dim, self.a_dim
+        nc, na, nd, ng = C.e.n_params, A.e.n_params, D.net.n_params, G.net.n_params
+        cur = torch.cuda.current_stream()
+        side = self._get(("side_stream",), lambda: torch.cuda.Stream())
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):                            # D step
+            dargs, wd, lpd = self._disc_args(D, b_g, b_s_, b_s, b_a, smooth, idx)
+            wd.grad = self.bucket("c2d", nd)
+            self._timed("disc_step_rows", lambda: check(lib.rlgan_disc_step_rows(dargs, _stream()), "rlgan_disc_step_rows"))
+            launch_wgrads([wgrad_job(D.net, wd)], S, Ad)
+            self._reduce_exchange_apply([reduce_job(D.net, wd, lpd, lpd.numel(), self._inv_gb(n), self.losses[self.LOSS_D_STEP:])],
+                                        wd.grad, [adam_job(D.net, wd.grad, D.m, D.v, D.step, D.lr)])
+        cargs, wc, wa, lpc = self._critic_args(C, A, b_s, b_a, b_r, b_s_, idx)    # critic step
+        bc = self.bucket("c2c", nc + (na if wa is not None else 0))
+        wc.grad = bc[:nc]
+        if wa is not None:
+            wa.grad = bc[nc:]
+        self._timed("critic_step_rows", lambda: check(lib.rlgan_critic_step_rows(cargs, _stream()), "rlgan_critic_step_rows"))
+        wj, rj = self._critic_jobs(C, A, wc, wa, lpc, n)
+        launch_wgrads(wj, S, Ad)
+        self._reduce_exchange_apply(rj, bc, self._critic_apply_jobs(C, A, wc, wa))
+        with torch.cuda.stream(side):                            # G step (reads the D the side stream just updated)
+            gargs, wg, lpg = self._gen_args(G, D, b_s, b_a, idx)
+            wg.grad = self.bucket("c2g", ng)
+            self._timed("gen_step_rows", lambda: check(lib.rlgan_gen_step_rows(gargs, _stream()), "rlgan_gen_step_rows"))
+            launch_wgrads([wgrad_job(G.net, wg)], S, Ad)
+            self._reduce_exchange_apply([reduce_job(G.net, wg, lpg, lpg.numel(), self._inv_gb(n), self.losses[self.LOSS_G_STEP:])],
+                                        wg.grad, [adam_job(G.net, wg.grad, G.m, G.v, G.step, G.lr)])
+        aargs, wa2 = self._actor_args(A, C, b_s, idx)            # actor step (reads the critic and actor just updated)
+        wa2.grad = self.bucket("c2a", na)
+        self._timed("actor_step_rows", lambda: check(lib.rlgan_actor_step_rows(aargs, _stream()), "rlgan_actor_step_rows"))
+        launch_wgrads([wgrad_job(A.e, wa2)], S, Ad)
+        self._reduce_exchange_apply([reduce_job(A.e, wa2)], wa2.grad, [self._actor_apply_job(A, wa2)])
+        cur.wait_stream(side)
 
     def _reduce_exchange_apply(self, reduce_jobs, bucket: torch.Tensor, apply_jobs) -> None:
         """Chunk reduction -> sum over ranks -> optimizers.  With one rank nothing happens in between, so

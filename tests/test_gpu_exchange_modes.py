@@ -27,7 +27,7 @@ for _ in range(3):
 L.capture()
 for _ in range(4):
     L.step()
-out = dict(losses=L.losses(), symm=bool(L.engine.exchange.symm), actor=L.actor.e.get_flat().tolist()[:64], gen=L.gen.net.get_flat().tolist()[:64])
+out = dict(losses=L.losses(), symm=bool(L.engine.exchange.symm), chains=bool(L.engine.two_chains), actor=L.actor.e.get_flat().tolist()[:64], gen=L.gen.net.get_flat().tolist()[:64])
 print("RESULT " + json.dumps(out))
 dist.destroy_process_group()
 """ % ROOT
@@ -45,6 +45,8 @@ def test_exchange_modes_leave_a_one_rank_update_untouched():
     plain = _run(29551)
     rccl = _run(29552, RLGAN_FORCE_EXCHANGE="1")
     symm = _run(29553, RLGAN_FORCE_EXCHANGE="1", RLGAN_EXCHANGE="symm")
+    chains = _run(29554, RLGAN_FORCE_EXCHANGE="1", RLGAN_CHAINS="2")     # critic->actor and D->G as two chains on two streams
     assert not plain["symm"] and not rccl["symm"] and symm["symm"]
-    for other in (rccl, symm):
+    assert chains["chains"] and not rccl["chains"]
+    for other in (rccl, symm, chains):
         assert other["losses"] == plain["losses"] and other["actor"] == plain["actor"] and other["gen"] == plain["gen"]
