@@ -142,10 +142,12 @@ class StepEngine:
         self._ws: Dict[Tuple, object] = {}
         self.losses = torch.zeros(8, dtype=torch.float32, device=device())
         self.kernel_events = None     # set to {} to record (start, end) event pairs per kernel launch
-        # RLGAN_CHAINS=2 (opt-in, only with more than one rank): the update runs as two chains on two streams, critic
-        # step -> actor step and D step -> G step, each step with its own exchange, so that one chain computes while the
-        # other waits for its all-reduce.  On one GPU the two fused phase launches are faster (nothing to wait for).
-        self.two_chains = os.environ.get("RLGAN_CHAINS") == "2"
+        # With more than one rank the update runs as two chains on two streams, critic step -> actor step and D step ->
+        # G step, each step with its own exchange, so that one chain computes while the other waits for its all-reduce
+        # (RLGAN_CHAINS=1 keeps the two fused phase launches with one exchange each; RLGAN_CHAINS=2 forces the chains,
+        # e.g. for a one-rank rehearsal).  On one GPU the fused phases are faster: there is nothing to wait for.
+        chains = os.environ.get("RLGAN_CHAINS", "")
+        self.two_chains = chains == "2" or (chains != "1" and self.exchange.world > 1)
 
     def _timed(self, name: str, launch):
         """Run `launch()`; when kernel_events is a dict, bracket it with events on the launch stream."""
