@@ -64,3 +64,14 @@ for B in [int(v) for v in sys.argv[1:]] or [32, 4096]:
     print(f"B={B:5d}: A_pred.learn {ta:9.1f} us   critic.learn (features given) {tc:8.1f} us   actor.learn (features given) {tac:8.1f} us")
     print(f"B={B:5d}: whole learning iteration (GAN half + inverse model + critic + actor): one by one {tfe:9.1f} us, as a graph {tfg:9.1f} us"
           f" = {B / tfg * 1e6:9.0f} transitions/s")
+    # the acting side of the loop for B environments at once (Curious_GAN_mario.py:63-69): action, predicted frame,
+    # intrinsic reward, LSTM state; the frames come from the uint8 ring
+    c0 = torch.zeros(B, 256, device="cuda"); h0 = torch.zeros(B, 256, device="cuda")
+    def acting():
+        ph = st.forward(mem.ref(idx))
+        act = actor.actions(ph)[:, :a_dim].contiguous()
+        g_img = G.predict_batch(ph, act)
+        D.determine_batch(mem.ref(idx), act, g_img)
+        actor.LSTM_unit.step_batch(ph, c0, h0)
+    tact = timeit(acting)
+    print(f"B={B:5d}: acting side (encoder, actor, predicted frame, 1 - D, LSTM step) {tact:9.1f} us = {B / tact * 1e6:9.0f} env-steps/s of compute")
