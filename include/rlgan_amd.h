@@ -41,7 +41,8 @@ enum {
   RLGAN_E_DIMS = -2,     /* state/action dims outside what the kernels are built for */
   RLGAN_E_KIND = -3,     /* unknown network kind */
   RLGAN_E_NOTFULL = -4,  /* replay sample before the ring is full (Curious_GAN.py:167 assert) */
-  RLGAN_E_ALIGN = -5     /* row count / leading dimension not as documented */
+  RLGAN_E_ALIGN = -5,    /* row count / leading dimension not as documented */
+  RLGAN_E_SCRATCH = -6   /* size beyond the fixed device scratch of an allocation-free entry point */
 };
 
 /* sizes of the three device images of one network */
@@ -447,6 +448,14 @@ int rlgan_deconv_gather(const rlgan_deconv_t* deconv, const float* dy, const flo
  * (bias gradient of a layer); partial: scratch of 512 * n_cols floats. */
 int rlgan_column_sums(const float* dy, const float* y_relu, int64_t rows, int32_t n_cols, float* partial, float* out,
                       void* stream);
+/* rlgan_column_sums without the `partial` argument, for callers that cannot allocate device memory (code under
+ * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  The
+ * partial sums go to a fixed 512 KiB array inside the library (512 partial rows x 256 columns, one copy per GPU,
+ * held until the process ends), so n_cols <= 256 or RLGAN_E_SCRATCH; `rows` is unlimited.  Same kernels, same
+ * order of additions and same bits as rlgan_column_sums.  The call allocates and frees nothing.  All calls on one
+ * GPU share that array: two calls whose kernels may overlap on one GPU (different streams) race; calls on one
+ * stream, or ordered by events, do not. */
+int rlgan_column_sums_noalloc(const float* dy, const float* y_relu, int64_t rows, int32_t n_cols, float* out, void* stream);
 /* dst[i] = map[i] >= 0 ? src[map[i]] : 0   (a gradient image back into canonical parameter order) */
 int rlgan_gather_map(const float* src, const int32_t* map, int32_t n, float* dst, void* stream);
 

@@ -9,8 +9,16 @@
 #include "fastdiv.h"
 #include "rlgan_device.h"
 #include "rlgan_host.h"
+#include <atomic>
 
 using namespace rlgan;
+
+// Partial sums of rlgan_column_sums_noalloc: the library's own copy of the `partial` argument of
+// rlgan_column_sums at its largest (512 partial rows of 256 columns, 512 KiB).  Every GPU the library runs
+// on holds one copy at its own address until the process ends; in host code the name below is only a handle
+// for hipGetSymbolAddress, never an address a kernel may be given.
+constexpr int COLSUM_PARTS = 512, COLSUM_MAX_COLS = 256;
+static __device__ __align__(256) float scratch[COLSUM_PARTS * COLSUM_MAX_COLS];
 
 namespace {
 
@@ -231,7 +239,32 @@ __global__ void one_minus_sigmoid_kernel(const float* __restrict__ logits, int l
 }
 
 inline int launched() { return (int)hipGetLastError(); }
-constexpr int COLSUM_PARTS = 512;
+
+// device address of `scratch` on the current GPU, looked up once per device
+constexpr int MAX_DEVICES = 64;
+std::atomic<float*> scratch_ptr[MAX_DEVICES];
+int scratch_here(float** out) {
+  int dev = -1;
+  if (const hipError_t e = hipGetDevice(&dev)) return (int)e;
+  if (dev < 0 || dev >= MAX_DEVICES) return RLGAN_E_ARG;
+  float* p = scratch_ptr[dev].load(std::memory_order_acquire);
+  if (!p) {
+    if (const hipError_t e = hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch))) return (int)e;
+    if (!p) return (int)hipErrorInvalidSymbol;
+    scratch_ptr[dev].store(p, std::memory_order_release);
+  }
+  *out = p;
+  return 0;
+}
+
+int column_sums(const float* dy, const float* y_relu, int64_t rows, int32_t n_cols, float* partial, float* out, void* stream) {
+  const long long per = ((long long)rows + COLSUM_PARTS - 1) / COLSUM_PARTS;
+  const int parts = (int)(((long long)rows + per - 1) / per);
+  hipLaunchKernelGGL(colsum_part_kernel, dim3(parts), dim3(256), 0, (hipStream_t)stream, dy, y_relu, (long long)rows, n_cols, per, partial);
+  if (const int rc = launched()) return rc;
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, parts, n_cols, out);
+  return launched();
+}
 
 }  // namespace
 
@@ -292,13 +325,16 @@ int rlgan_deconv_gather(const rlgan_deconv_t* d, const float* dy, const float* y
 
 int rlgan_column_sums(const float* dy, const float* y_relu, int64_t rows, int32_t n_cols, float* partial, float* out, void* stream) {
   if (!dy || !partial || !out || rows <= 0 || n_cols <= 0) return RLGAN_E_ARG;
-  if (n_cols > 256) return RLGAN_E_DIMS;
-  const long long per = ((long long)rows + COLSUM_PARTS - 1) / COLSUM_PARTS;
-  const int parts = (int)(((long long)rows + per - 1) / per);
-  hipLaunchKernelGGL(colsum_part_kernel, dim3(parts), dim3(256), 0, (hipStream_t)stream, dy, y_relu, (long long)rows, n_cols, per, partial);
-  if (const int rc = launched()) return rc;
-  hipLaunchKernelGGL(colsum_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, parts, n_cols, out);
-  return launched();
+  if (n_cols > COLSUM_MAX_COLS) return RLGAN_E_DIMS;
+  return column_sums(dy, y_relu, rows, n_cols, partial, out, stream);
+}
+
+int rlgan_column_sums_noalloc(const float* dy, const float* y_relu, int64_t rows, int32_t n_cols, float* out, void* stream) {
+  if (!dy || !out || rows <= 0 || n_cols <= 0) return RLGAN_E_ARG;
+  if (n_cols > COLSUM_MAX_COLS) return RLGAN_E_SCRATCH;     // a partial row would not fit its slot of the fixed array
+  float* partial = nullptr;
+  if (const int rc = scratch_here(&partial)) return rc;
+  return column_sums(dy, y_relu, rows, n_cols, partial, out, stream);
 }
 
 int rlgan_gather_map(const float* src, const int32_t* map, int32_t n, float* dst, void* stream) {

@@ -42,6 +42,7 @@ const char* rlgan_error_string(int code) {
     case RLGAN_E_KIND: return "unknown network kind";
     case RLGAN_E_NOTFULL: return "Memory has not been fulfilled";
     case RLGAN_E_ALIGN: return "row count or leading dimension not as documented";
+    case RLGAN_E_SCRATCH: return "size beyond the fixed device scratch of the allocation-free entry point (rlgan_column_sums_noalloc: n_cols <= 256)";
     default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
   }
 }
