@@ -239,7 +239,8 @@ int rlgan_apply(const rlgan_apply_job_t* jobs, int n_jobs, void* stream);
  * per-tile loss sums of a *_rows call into the loss value (tf.reduce_mean, Curious_GAN.py:33-40). */
 int rlgan_sum_parts(const float* parts, int n_parts, int n_sums, float scale, float* out, void* stream);
 
-/* target <- tau*eval + (1-tau)*target when (counter[0]-1) % period == 0 (counter NULL: always). */
+/* target <- tau*eval + (1-tau)*target when (counter[0]-1) % period == 0 (counter NULL: always).  map_f and target_wf
+ * may both be NULL for parameters that are used from their canonical vector alone (no fragment image to follow). */
 int rlgan_target_update(float* target_canon, const float* eval_canon, int n_params, float tau,
                         const int32_t* counter, int period, const int32_t* map_f, float* target_wf,
                         void* stream);

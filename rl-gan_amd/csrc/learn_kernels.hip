@@ -641,8 +641,10 @@ __global__ void target_update_kernel(float* __restrict__ tc, const float* __rest
   if (p >= n) return;
   const float w = tau == 1.f ? ec[p] : tau * ec[p] + (1.f - tau) * tc[p];
   tc[p] = w;
-  const int of = map_f[p];
-  if (of >= 0) twf[of] = w;
+  if (map_f) {
+    const int of = map_f[p];
+    if (of >= 0) twf[of] = w;
+  }
 }
 
 __global__ void pack_kernel(const float* __restrict__ canon, int n, const int32_t* __restrict__ map_f,
@@ -876,7 +878,7 @@ int rlgan_sum_parts(const float* parts, int n_parts, int n_sums, float scale, fl
 
 int rlgan_target_update(float* target_canon, const float* eval_canon, int n_params, float tau,
                         const int32_t* counter, int period, const int32_t* map_f, float* target_wf, void* stream) {
-  if (!target_canon || !eval_canon || !map_f || !target_wf || n_params <= 0 || (counter && period <= 0)) return RLGAN_E_ARG;
+  if (!target_canon || !eval_canon || (map_f != nullptr) != (target_wf != nullptr) || n_params <= 0 || (counter && period <= 0)) return RLGAN_E_ARG;
   hipLaunchKernelGGL(target_update_kernel, dim3(cdiv(n_params, 256)), dim3(256), 0, (hipStream_t)stream,
                      target_canon, eval_canon, n_params, tau, counter, period, map_f, target_wf);
   return launched();

@@ -41,34 +41,13 @@ class GradExchange:
         self.group = group
         self.world = dist.get_world_size(group) if self.enabled else 1
         self.rank = dist.get_rank(group) if self.enabled else 0
-        # RLGAN_EXCHANGE=symm (opt-in): buckets live in PyTorch's symmetric memory and are summed by its one-shot
-        # all-reduce (every rank reads every peer's bucket over xGMI and adds them in rank order) instead of RCCL's
-        # all-reduce: one kernel, no ring, for messages this small.  Off by default: it has only been exercised with one
-        # rank (symmetric memory refuses ranks that share a GPU, so a one-GPU box cannot rehearse more).
-        self.symm = self.enabled and os.environ.get("RLGAN_EXCHANGE", "rccl") == "symm"
-        self._symm_out = {}
 
     def new_bucket(self, n: int) -> torch.Tensor:
         """A zeroed flat fp32 bucket of n floats for `all_reduce_sum`."""
-        b = torch.zeros(n, dtype=torch.float32, device=device())
-        if self.symm:
-            import torch.distributed._symmetric_memory as sm
-            grp = self.group if self.group is not None else self.dist.group.WORLD
-            stage = sm.empty(n, dtype=torch.float32, device=device())     # what the peers read; `b` receives the sum
-            sm.rendezvous(stage, grp.group_name)
-            self._symm_out[b.data_ptr()] = (grp.group_name, stage)
-        return b
+        return torch.zeros(n, dtype=torch.float32, device=device())
 
     def all_reduce_sum(self, bucket: torch.Tensor) -> None:
         if not self.enabled:
-            return
-        if self.symm and bucket.data_ptr() in self._symm_out:
-            # The stage is written again only two exchanges later (the two phases have a bucket each), and a rank gets
-            # past the entry barrier of the exchange in between only once every peer has left this one: no peer can
-            # still be reading the stage then.
-            name, stage = self._symm_out[bucket.data_ptr()]
-            stage.copy_(bucket)
-            torch.ops.symm_mem.one_shot_all_reduce_out(stage, "sum", name, bucket)
             return
         if bucket.is_cuda and self.dist.get_backend(self.group) == "gloo":
             # test rigs only (several ranks on one GPU): gloo moves the bucket through host memory
@@ -136,18 +115,25 @@ class StepEngine:
 
     LOSS_CRITIC, LOSS_D_STEP, LOSS_G_STEP, LOSS_D_EVAL, LOSS_G_EVAL = range(5)
 
-    def __init__(self, s_dim: int, a_dim: int, exchange: Optional[GradExchange] = None):
+    def __init__(self, s_dim: int, a_dim: int, exchange: Optional[GradExchange] = None, chains: Optional[int] = None):
         self.s_dim, self.a_dim = s_dim, a_dim
         self.exchange = exchange or GradExchange()
         self._ws: Dict[Tuple, object] = {}
         self.losses = torch.zeros(8, dtype=torch.float32, device=device())
         self.kernel_events = None     # set to {} to record (start, end) event pairs per kernel launch
-        # With more than one rank the update runs as two chains on two streams, critic step -> actor step and D step ->
-        # G step, each step with its own exchange, so that one chain computes while the other waits for its all-reduce
-        # (RLGAN_CHAINS=1 keeps the two fused phase launches with one exchange each; RLGAN_CHAINS=2 forces the chains,
-        # e.g. for a one-rank rehearsal).  On one GPU the fused phases are faster: there is nothing to wait for.
-        chains = os.environ.get("RLGAN_CHAINS", "")
-        self.two_chains = chains == "2" or (chains != "1" and self.exchange.world > 1)
+        # Form of a multi-rank update.  chains = 1 (default): the two fused phase launches {critic, D} and {actor, G}
+        # with one gradient exchange each.  chains = 2 (argument, or RLGAN_CHAINS=2): critic step -> actor step and
+        # D step -> G step as two chains on two streams, each step with its own exchange, so that one chain computes
+        # while the other waits for its all-reduce.  Both give the same bits; on one rank there is nothing to wait
+        # for and the fused phases are always used unless the exchange is forced on.
+        self.set_chains(chains if chains is not None else int(os.environ.get("RLGAN_CHAINS", "1")))
+
+    def set_chains(self, chains: int) -> None:
+        """Select the form of the multi-rank update (1 = fused phases, 2 = two chains); graphs captured before the
+        call keep the form they were captured with."""
+        if chains not in (1, 2):
+            raise ValueError("chains must be 1 or 2")
+        self.two_chains = chains == 2
 
     def _timed(self, name: str, launch):
         """Run `launch()`; when kernel_events is a dict, bracket it with events on the launch stream."""

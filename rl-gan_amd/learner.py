@@ -161,9 +161,12 @@ class CuriousLearner:
         self.engine._timed("rollout_eval_rows", lambda: check(
             lib.rlgan_rollout_eval_rows(act, ev, sample, None, _stream()), "rlgan_rollout_eval_rows"))
 
-    def update(self) -> None:
-        """One minibatch update with its two losses (Curious_GAN.py:199-213), without acting.
-        Losses: self.engine.losses."""
+    def update(self, redraw: bool = True) -> None:
+        """One minibatch update with its two losses (Curious_GAN.py:199-213), without acting: a fresh index draw
+        (`M.sample`, Curious_GAN.py:199; redraw=False keeps the indices the last acting launch drew), the four steps,
+        the two evaluations.  Losses: self.engine.losses."""
+        if redraw:
+            check(lib.rlgan_rollout_eval_rows(None, None, self._sample_args(), None, _stream()), "rlgan_rollout_eval_rows")
         self._update_body()
         s, s_, g, a = self._ring_fields()
         self.engine.gan_eval(self.gen, self.disc, g, s_, s, a, self.cfg.smooth, self.idx)

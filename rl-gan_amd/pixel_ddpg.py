@@ -209,6 +209,11 @@ class PixelActor:
         self.eval_net.backward(self._acts, da, need_dx=False)
         self.t_replace_counter.add_(1)
         launch_apply([o.job(-self.lr, self.t_replace_counter, self.t_replace_iter) for o in self._opt])
+        # e_params / t_params are collected by scope (Conv_model.py:708-709), so the periodic tf.assign list also copies
+        # the eval net's LSTM cell into the target's (Conv_model.py:752-753) although no optimizer touches either
+        e, t = self.LSTM_unit.cell, self.LSTM_unit_.cell
+        check(lib.rlgan_target_update(t.canon.data_ptr(), e.canon.data_ptr(), e.n_params, 1.0, self.t_replace_counter.data_ptr(),
+                                      self.t_replace_iter, None, None, _stream()), "rlgan_target_update")
 
 
 class PixelCritic:

@@ -5,7 +5,10 @@
 mode `oracle`: the NumPy restatement computes the gradients of this rank's shard of the minibatch,
 the flat gradient buckets go through rl_gan_amd's GradExchange (gloo, CPU tensors) and every rank
 applies the summed gradients.  mode `engine`: the HIP path does the same on cuda:0 (all ranks share
-the one GPU of the test box; gloo moves the buckets).  Each rank saves its final weights.
+the one GPU of the test box; gloo moves the buckets).  mode `learner`: every rank runs a `CuriousLearner` of its
+own (its own environments, replay ring and index stream) for <n_updates> iterations at <batch> rows per rank and also
+saves the weights it started from and the minibatch rows of every update.  Each rank saves its final weights.
+RLGAN_CHAINS in the environment selects the form of the multi-rank update (1 fused phases, 2 two chains).
 """
 import os
 import sys
@@ -77,10 +80,33 @@ def run_engine(rank, world, n_updates, B):
     return {k: np.asarray(v) for k, v in w.items()}, np.array(losses)
 
 
+def run_learner(rank, world, n_updates, B):
+    import rl_gan_amd as R
+    torch.cuda.set_device(0)
+    cfg = R.LearnerConfig(n_env=B, batch_size=B, memory_capacity=4 * B, seed=9, max_ep_steps=6, replace_iter_a=2, replace_iter_c=3)
+    L = R.CuriousLearner(cfg)
+    assert L.exchange.world == world and L.exchange.rank == rank
+    nets = lambda: {"actor_e": L.actor.e.get_flat(), "actor_t": L.actor.t.get_flat(), "critic_e": L.critic.e.get_flat(),
+                    "critic_t": L.critic.t.get_flat(), "gen": L.gen.net.get_flat(), "disc": L.disc.net.get_flat()}
+    w0 = {"init_" + k: v for k, v in nets().items()}
+    L.fill()
+    losses, batches = [], []
+    for _ in range(n_updates):
+        batches.append(L.memory._data[L.idx][:, :25].cpu().numpy())     # the rows the coming update trains on
+        L.step()
+        l = L.losses()                                                   # a collective: global means
+        losses.append([l["critic"], l["D_step"], l["G_step"], l["D_loss"], l["G_loss"]])
+    out = {k: np.asarray(v) for k, v in nets().items()}
+    out.update(w0)
+    out["batches"] = np.stack(batches)
+    out["idx_seed"] = np.array([cfg.seed + 7919 * rank])
+    return out, np.array(losses)
+
+
 def main():
     mode, rank, world, port, out, n_updates, B = sys.argv[1], *map(int, sys.argv[2:5]), sys.argv[5], int(sys.argv[6]), int(sys.argv[7])
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
-    w, losses = (run_oracle if mode == "oracle" else run_engine)(rank, world, n_updates, B)
+    w, losses = {"oracle": run_oracle, "engine": run_engine, "learner": run_learner}[mode](rank, world, n_updates, B)
     np.savez(out, losses=losses, **w)
     dist.barrier()
     dist.destroy_process_group()

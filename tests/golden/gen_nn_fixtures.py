@@ -64,6 +64,10 @@ def run(seed, B, iters, ddpg_only):
     for k in NETS:
         out[f"final_{k}"] = ag.flat(k)[::FINAL_STRIDE].astype(np.float32)
         out[f"final_sums_{k}"] = sums(ag.flat(k))
+    if not ddpg_only:
+        # per-entry bound on what gradient errors within 1e-5 may do to the Adam-trained weights (oracle/optim.py)
+        out["final_allow_gen"] = ag.opt_g.allow[::FINAL_STRIDE].astype(np.float32)
+        out["final_allow_disc"] = ag.opt_d.allow[::FINAL_STRIDE].astype(np.float32)
     return out
 
 

@@ -56,15 +56,50 @@ class Pair:
         self.D = AdamState(net=mk(_lib.NET_DISCRIMINATOR, o.disc_spec, o.disc, True), lr=self.hp.lr_d)
         self.eng = StepEngine(7, 2)
 
-    def check_weights(self, what="", adam_steps=1):
-        """Adam divides by sqrt(v): an entry whose gradient is rounding noise still moves by about
-        lr per step, in a direction the noise decides.  Adam-trained weights therefore get an extra
-        absolute allowance of a quarter of lr per step taken; gradients are compared strictly."""
+    def check_flats(self, flats, what="", adam_steps=None):
+        """Six flat weight vectors (dict by name) against the oracle's.  RMSProp-trained networks: the plain
+        tolerance.  Adam-trained ones (generator, discriminator): plus, per entry, the bound the oracle's optimizer
+        keeps on what gradient errors within RTOL may do to that entry (oracle/optim.py, Adam.allow) -- about a
+        step where the gradient is rounding noise, next to nothing where it is not."""
         o = self.o
-        ad = 0.25 * adam_steps
-        close(self.A.e.get_flat(), o.flat("actor_e"), what=what + " actor_e")
-        close(self.A.t.get_flat(), o.flat("actor_t"), what=what + " actor_t")
-        close(self.C.e.get_flat(), o.flat("critic_e"), what=what + " critic_e")
-        close(self.C.t.get_flat(), o.flat("critic_t"), what=what + " critic_t")
-        close(self.G.net.get_flat(), o.flat("gen"), what=what + " gen", atol=ad * self.hp.lr_g)
-        close(self.D.net.get_flat(), o.flat("disc"), what=what + " disc", atol=ad * self.hp.lr_d)
+        for k in ("actor_e", "actor_t", "critic_e", "critic_t"):
+            close(flats[k], o.flat(k), what=f"{what} {k}")
+        close(flats["gen"], o.flat("gen"), what=what + " gen", atol=o.opt_g.allow)
+        close(flats["disc"], o.flat("disc"), what=what + " disc", atol=o.opt_d.allow)
+
+    def check_weights(self, what="", adam_steps=None):
+        self.check_flats({"actor_e": self.A.e.get_flat(), "actor_t": self.A.t.get_flat(), "critic_e": self.C.e.get_flat(),
+                          "critic_t": self.C.t.get_flat(), "gen": self.G.net.get_flat(), "disc": self.D.net.get_flat()}, what)
+
+    def check_slots(self, what="", rtol=RTOL):
+        """Optimizer slots against the oracle's: RMSProp's mean square (both of the critic's train-op and the
+        actor's own), Adam's two moments.  They are linear / quadratic in the gradients, so after a first update from
+        identical weights the plain tolerance holds.  Later updates start from weights that already differ where Adam
+        took a noise-decided step (see check_flats), which moves every later gradient a little: callers pass a wider
+        rtol there and say what they measured."""
+        o = self.o
+        close(self.C.ms.cpu().numpy(), o.opt_c.ms, what=what + " critic ms", rtol=rtol)
+        if self.C.ms_actor is not None:
+            close(self.C.ms_actor.cpu().numpy(), o.opt_c_actor.ms, what=what + " critic train-op actor ms", rtol=rtol)
+        close(self.A.ms.cpu().numpy(), o.opt_a.ms, what=what + " actor ms", rtol=rtol)
+        for st, opt, n in ((self.D, o.opt_d, "disc"), (self.G, o.opt_g, "gen")):
+            close(st.m.cpu().numpy(), opt.m, what=f"{what} {n} m", rtol=rtol)
+            close(st.v.cpu().numpy(), opt.v, what=f"{what} {n} v", rtol=2 * rtol)     # v is quadratic in g: twice its relative error
+            assert int(st.step.item()) == opt.t
+
+    def check_deltas(self, before, what=""):
+        """The applied updates themselves, w_after - w_before, against the oracle's: the weights are O(0.1) and a step
+        is O(lr), so comparing weights alone would let the optimizer arithmetic be off by percents.  Tolerance: RTOL of
+        the update (with the tensor's largest update as floor) plus one float32 ulp of the weight, which is what
+        storing w in float32 costs; Adam-trained networks get the oracle's gradient-noise bound on top."""
+        o = self.o
+        now = {"actor_e": self.A.e.get_flat(), "critic_e": self.C.e.get_flat(), "gen": self.G.net.get_flat(), "disc": self.D.net.get_flat()}
+        for k, w in now.items():
+            w0 = np.asarray(before[k], dtype=np.float64)
+            ref = o.flat(k) - w0
+            ulp = np.spacing(np.abs(w).astype(np.float32)).astype(np.float64)
+            extra = {"gen": o.opt_g.allow, "disc": o.opt_d.allow}.get(k, 0.0)
+            close(w.astype(np.float64) - w0, ref, what=f"{what} delta {k}", atol=ulp + extra)
+
+    def snapshot(self):
+        return {"actor_e": self.A.e.get_flat(), "critic_e": self.C.e.get_flat(), "gen": self.G.net.get_flat(), "disc": self.D.net.get_flat()}

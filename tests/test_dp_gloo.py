@@ -23,11 +23,12 @@ def free_port():
         return s.getsockname()[1]
 
 
-def run_ranks(mode, world, n_updates, B, tmp_path, timeout=300):
+def run_ranks(mode, world, n_updates, B, tmp_path, timeout=300, env=None):
     port = free_port()
+    env = dict(os.environ, **(env or {}))
     outs = [str(tmp_path / f"rank{r}.npz") for r in range(world)]
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dp_worker.py"), mode, str(r), str(world), str(port),
-                               outs[r], str(n_updates), str(B)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+                               outs[r], str(n_updates), str(B)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env)
              for r in range(world)]
     logs = []
     for p in procs:

@@ -46,7 +46,7 @@ def test_fused_acting_step_matches_oracle_sequence():
     for t in range(5):
         slots = (np.arange(n) + t * n) % cap
         if t >= 3:       # rows of steps 3 and 4 are still in the ring (cap 256 holds the last 256 rows)
-            close(data[slots], rows_ref[t], rtol=2e-5, what=f"replay rows of step {t}")
+            close(data[slots], rows_ref[t], what=f"replay rows of step {t}")
 
 
 def test_reference_shaped_api_one_training_iteration():
@@ -108,8 +108,8 @@ def test_reference_shaped_api_one_training_iteration():
         curious_r = r + ITA * det[0]
         # oracle on the same transition
         close(a if t else a, a, what="noop")
-        close(g, o.predict(s[None].astype(np.float32), a[None].astype(np.float32))[0], rtol=2e-5, what="predict")
-        close(det, o.determine(s[None].astype(np.float32), a[None].astype(np.float32), g[None]), rtol=2e-5, what="determine")
+        close(g, o.predict(s[None].astype(np.float32), a[None].astype(np.float32))[0], what="predict")
+        close(det, o.determine(s[None].astype(np.float32), a[None].astype(np.float32), g[None]), what="determine")
         so_, ro, do = oenv.step(a)
         np.testing.assert_allclose(s_, so_, atol=1e-12)
         assert r == ro and done == do
@@ -187,7 +187,7 @@ def test_vectorised_learner_tracks_the_oracle_loop():
     for it in range(3):
         assert L.memory.pointer == O.pointer and L.ctr.tolist() == [O.pointer, O.step_count]
         np.testing.assert_array_equal(L.idx.cpu().numpy(), O.idx)                       # bit-exact draws
-        close(L.memory._data[:, :25].cpu().numpy(), O.ring, rtol=2e-5, what=f"ring before update {it}")
+        close(L.memory._data[:, :25].cpu().numpy(), O.ring, what=f"ring before update {it}")
         np.testing.assert_array_equal(L.env.goal.cpu().numpy().reshape(-1, 2), O.env.goal)
         np.testing.assert_array_equal(L.ep_t.cpu().numpy(), O.ep_t)
         assert int(L.n_resets.item()) == O.n_resets and abs(float(L.var.item()) - O.var) < 1e-15
@@ -195,13 +195,37 @@ def test_vectorised_learner_tracks_the_oracle_loop():
         L.step()                     # update on the same minibatch, its losses, the next acting step, the next draw
         O.act()
         l = L.losses()
-        close(l["critic"], ref["critic_loss"], what=f"critic loss {it}", rtol=5e-5)
-        close(l["D_loss"], ref["D_loss"], what=f"D_loss {it}", rtol=2e-5)
-        close(l["G_loss"], ref["G_loss"], what=f"G_loss {it}", rtol=2e-5)
+        close(l["critic"], ref["critic_loss"], what=f"critic loss {it}")
+        close(l["D_loss"], ref["D_loss"], what=f"D_loss {it}")
+        close(l["G_loss"], ref["G_loss"], what=f"G_loss {it}")
     assert O.n_resets > 0
-    close(L.actor.e.get_flat(), ag.flat("actor_e"), rtol=5e-5, what="actor weights")
-    close(L.critic.e.get_flat(), ag.flat("critic_e"), rtol=5e-5, what="critic weights")
+    close(L.actor.e.get_flat(), ag.flat("actor_e"), what="actor weights")
+    close(L.critic.e.get_flat(), ag.flat("critic_e"), what="critic weights")
     np.testing.assert_array_equal(L.actor.t.get_flat(), L.actor.e.get_flat())       # copied on calls 0 and 2
+
+
+def test_update_without_acting_draws_fresh_indices():
+    """`CuriousLearner.update()` samples before it learns, like the reference (Curious_GAN.py:199): consecutive calls
+    train on consecutive draws of the replay's MT19937 stream, never on the same minibatch twice."""
+    import rl_gan_amd as R
+    cfg = R.LearnerConfig(n_env=32, batch_size=24, memory_capacity=64, seed=11)
+    L = R.CuriousLearner(cfg)
+    L.fill()
+    draws = [L.idx.cpu().numpy().copy()]
+    for _ in range(3):
+        L.update()
+        draws.append(L.idx.cpu().numpy().copy())
+    L.update(redraw=False)
+    np.testing.assert_array_equal(L.idx.cpu().numpy(), draws[-1])
+    rs = np.random.RandomState(cfg.seed)
+    for _ in range(64):                                   # find the draw the fill ended on, then follow the stream
+        if np.array_equal(rs.choice(cfg.memory_capacity, size=cfg.batch_size), draws[0]):
+            break
+    else:
+        raise AssertionError("the last draw of fill() is not on the NumPy stream")
+    for d in draws[1:]:
+        np.testing.assert_array_equal(d, rs.choice(cfg.memory_capacity, size=cfg.batch_size))
+    assert all(np.isfinite(v) for v in L.losses().values())
 
 
 def test_reference_training_loops_and_checkpoint_round_trip(tmp_path):

@@ -1,6 +1,6 @@
 """The gradient exchange inside the captured training step, rehearsed with one rank (RLGAN_FORCE_EXCHANGE=1 keeps the
-collective in the step): RCCL's all-reduce and the opt-in symmetric-memory one-shot all-reduce must both leave the
-update untouched when there is nothing to add (one rank), eager and as a replayed HIP graph."""
+collective in the step): RCCL's all-reduce, in the fused-phase form and in the two-chain form of the update, must leave
+the update untouched when there is nothing to add (one rank), eager and as a replayed HIP graph."""
 import json
 import os
 import subprocess
@@ -27,7 +27,7 @@ for _ in range(3):
 L.capture()
 for _ in range(4):
     L.step()
-out = dict(losses=L.losses(), symm=bool(L.engine.exchange.symm), chains=bool(L.engine.two_chains), actor=L.actor.e.get_flat().tolist()[:64], gen=L.gen.net.get_flat().tolist()[:64])
+out = dict(losses=L.losses(), chains=bool(L.engine.two_chains), actor=L.actor.e.get_flat().tolist()[:64], gen=L.gen.net.get_flat().tolist()[:64])
 print("RESULT " + json.dumps(out))
 dist.destroy_process_group()
 """ % ROOT
@@ -41,12 +41,10 @@ def _run(port, **env):
     return json.loads(line[7:])
 
 
-def test_exchange_modes_leave_a_one_rank_update_untouched():
+def test_exchange_forms_leave_a_one_rank_update_untouched():
     plain = _run(29551)
     rccl = _run(29552, RLGAN_FORCE_EXCHANGE="1")
-    symm = _run(29553, RLGAN_FORCE_EXCHANGE="1", RLGAN_EXCHANGE="symm")
     chains = _run(29554, RLGAN_FORCE_EXCHANGE="1", RLGAN_CHAINS="2")     # critic->actor and D->G as two chains on two streams
-    assert not plain["symm"] and not rccl["symm"] and symm["symm"]
     assert chains["chains"] and not rccl["chains"]
-    for other in (rccl, symm, chains):
+    for other in (rccl, chains):
         assert other["losses"] == plain["losses"] and other["actor"] == plain["actor"] and other["gen"] == plain["gen"]

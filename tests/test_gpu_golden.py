@@ -52,7 +52,9 @@ def test_curious_update_b16_matches_fixture():
     for k in NETS:
         v = w[k].get_flat()
         stride = int(round(v.size / fx[f"final_{k}"].size))
-        close(v[::stride], fx[f"final_{k}"], what=f"final {k}", atol=0.75e-4 if k in ("gen", "disc") else 0.0)
+        # Adam-trained weights: plus the fixture's per-entry bound on what gradient noise does to them (about a step
+        # where an entry's gradient is rounding noise, next to nothing elsewhere; oracle/optim.py, Adam.allow)
+        close(v[::stride], fx[f"final_{k}"], what=f"final {k}", atol=fx[f"final_allow_{k}"] if k in ("gen", "disc") else 0.0)
 
 
 def test_ddpg_update_b32_matches_fixture():

@@ -120,13 +120,18 @@ def test_actor_step(n, ad):
         np.testing.assert_allclose(L.canon.cpu().numpy(), want, rtol=0, atol=2e-7)
     for Lt, Le in zip(actor.target_net.layers, ev):
         assert torch.equal(Lt.canon, Le.canon)
+    # the target scope's LSTM cell is in t_params too (Conv_model.py:708-709,752-753): call 0 copied the eval cell over it
+    assert torch.equal(actor.LSTM_unit_.cell.canon, actor.LSTM_unit.cell.canon)
+    actor.LSTM_unit.cell.canon.mul_(0.5)                             # stands for a restored checkpoint changing the eval cell
     for _ in range(2):
         actor.learn(None, critic, phis=_dev(phis))
     for Lt, Le in zip(actor.target_net.layers, ev):
         assert not torch.equal(Lt.canon, Le.canon)                   # period 3: calls 1 and 2 do not copy
+    assert not torch.equal(actor.LSTM_unit_.cell.canon, actor.LSTM_unit.cell.canon)
     actor.learn(None, critic, phis=_dev(phis))
     for Lt, Le in zip(actor.target_net.layers, ev):
         assert torch.equal(Lt.canon, Le.canon)
+    assert torch.equal(actor.LSTM_unit_.cell.canon, actor.LSTM_unit.cell.canon)
 
 
 def test_steps_from_frames_and_action_choice():

@@ -21,6 +21,7 @@ def test_each_step_gradients_losses_and_weights(B):
     bt = dev(b)
     ft = dict(s=bt[:, :7], s_=bt[:, 7:14], g=bt[:, 14:21], a=bt[:, 21:23], r=bt[:, 23], cr=bt[:, 24])
     eng, o = p.eng, p.o
+    w0 = p.snapshot()
 
     # (1) critic step, including the continuation into the actor eval net
     ref = o.critic_learn(f["s"], f["a"], f["cr"], f["s_"])
@@ -29,6 +30,7 @@ def test_each_step_gradients_losses_and_weights(B):
     close(wa.grad.cpu().numpy(), ref["g_actor"], what="actor grads through the critic loss")
     close(eng.losses[eng.LOSS_CRITIC].item(), ref["loss"], what="TD loss")
     p.check_weights("after critic step")
+    p.check_deltas(w0, "critic step")
     assert int(p.C.counter.item()) == 1
 
     # (2) actor step
@@ -36,6 +38,7 @@ def test_each_step_gradients_losses_and_weights(B):
     wa2 = eng.actor_step(p.A, p.C, ft["s"])
     close(wa2.grad.cpu().numpy(), ref["g_actor"], what="policy grads")
     p.check_weights("after actor step")
+    p.check_deltas(w0, "critic + actor step")
 
     # (3) discriminator step
     ref = o.disc_learn(f["g"], f["s_"], f["s"], f["a"])
@@ -50,6 +53,8 @@ def test_each_step_gradients_losses_and_weights(B):
     close(wg.grad.cpu().numpy(), ref["g_gen"], what="G grads")
     close(eng.losses[eng.LOSS_G_STEP].item(), ref["loss"], what="G loss (pre-update)")
     p.check_weights("after G step")
+    p.check_deltas(w0, "all four steps")
+    p.check_slots("after the four steps")
 
     # (5), (6) post-update losses
     out = eng.gan_eval(p.G, p.D, ft["g"], ft["s_"], ft["s"], ft["a"]).cpu().numpy()
@@ -72,7 +77,10 @@ def test_three_fused_updates_track_the_oracle(B):
         close(l[p.eng.LOSS_CRITIC], ref["critic_loss"], what=f"it{it} critic loss")
         close(l[p.eng.LOSS_D_EVAL], ref["D_loss"], what=f"it{it} D_loss")
         close(l[p.eng.LOSS_G_EVAL], ref["G_loss"], what=f"it{it} G_loss")
-        p.check_weights(f"after update {it}", adam_steps=it + 1)
+        p.check_weights(f"after update {it}")
+        # strict after the first update; from the second on the generator's first moment is off by up to 1.2e-5 of its
+        # scale at batch 4096 (2 of 52,607 entries, measured), the echo of noise-decided Adam steps in the weights
+        p.check_slots(f"after update {it}", rtol=1e-5 if it == 0 else 3e-5)
     assert int(p.C.counter.item()) == 3 and int(p.A.counter.item()) == 3 and int(p.D.step.item()) == 3
     # target nets were copied on calls 0 (both) and 2 (actor) / 3 would be next for the critic
     np.testing.assert_array_equal(p.A.t.get_flat(), p.A.e.get_flat())
