@@ -60,6 +60,33 @@ def measured_hbm_traffic(kernel):
     return k["hbm_bytes_per_launch"] if k else None
 
 
+def measured_iteration_traffic():
+    """HBM bytes of one whole iteration (row passes, weight gradients, optimizers, tail) from the same counter file."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_v*_pmc_hbm.json")),
+                   key=lambda f: [int(x) for x in re.findall(r"\d+", os.path.basename(f))])
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        d = json.load(f)
+    return d.get("iteration_hbm_bytes")
+
+
+def measured_mfma_busy(kernel):
+    """Share of the matrix pipe's peak-clock cycles that held an MFMA during `kernel`, from the newest committed
+    counter run (profiles/*_pmc_mfma.json, rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES ... of this same command)."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_v*_pmc_mfma.json")),
+                   key=lambda f: [int(x) for x in re.findall(r"\d+", os.path.basename(f))])
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        k = json.load(f).get("kernels", {}).get(kernel.replace("_rows", "_kernel"))
+    return k.get("mfma_busy_frac") if k else None
+
+
 def cpu_baseline(budget_s=12.0):
     """The oracle's float32 update at batch 4096 on the host cores (NumPy + its BLAS threads)."""
     import numpy as np
@@ -142,16 +169,54 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        L.step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    def timed_region(steps):
+        """EXACTLY `steps` iterations between two barrier + synchronize pairs; seconds, the maximum over ranks."""
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            L.step()
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    def measure(steps):
+        """A short region (--steps 20 is under 4 ms) cannot raise the clocks by itself and one host hiccup is a large
+        share of it: besides the --warmup steps the loop first runs for a fixed 0.3 s, then the region of exactly
+        `steps` steps is timed `repeats` times back to back and the MEDIAN region is the one reported."""
+        if world == 1:
+            t_end = time.perf_counter() + 0.3
+            while time.perf_counter() < t_end:
+                L.step()
+            torch.cuda.synchronize()
+        else:
+            # every step holds collectives, so all ranks must take the same number of steps: time 50 of them (maximum
+            # over ranks, the same value everywhere) and derive the count for 0.3 s from that
+            per_step = timed_region(50) / 50
+            for _ in range(min(20000, int(0.3 / max(per_step, 1e-6)) + 1)):
+                L.step()
+        repeats = max(3, min(25, int(round(0.25 / (steps * 2e-4)))) | 1)     # odd; about a quarter of a second in all
+        regions = sorted(timed_region(steps) for _ in range(repeats))
+        return regions[len(regions) // 2], regions[0], regions[-1], repeats
+
+    dt, dt_min, dt_max, repeats = measure(args.steps)
+    forms = None
+    if world > 1 and launch == "graph":
+        # the other form of the multi-rank update (two chains on two streams, one exchange per step), same run, same
+        # measurement: the scaling record then shows which form the exchange latency favours
+        try:
+            L.engine.set_chains(2)
+            L._graph = None
+            L.capture()
+            dt2 = measure(args.steps)[0]
+            forms = {"fused_phases_ms_per_step": round(dt / args.steps * 1e3, 4), "two_chains_ms_per_step": round(dt2 / args.steps * 1e3, 4)}
+        except Exception as e:
+            print(f"[bench] two-chain form not timed ({type(e).__name__}: {e})", file=sys.stderr, flush=True)
+            torch.cuda.synchronize()
+        L.engine.set_chains(1)
 
     # per-kernel durations, measured live on the launch stream over a second, eager pass of the same loop
     L._graph = None
@@ -180,6 +245,7 @@ def main():
         out = {
             "metric": "learner updates/sec (batch 4096)", "value": round((1 if args.strong else world) * args.steps / dt, 2), "unit": "updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "repeats": repeats, "ms_per_step_min": round(dt_min / args.steps * 1e3, 4), "ms_per_step_max": round(dt_max / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "curious_gan_ddpg_arm_b4096", "envs_per_gpu": n_env, "batch_per_gpu": batch,
                        "replay_rows_per_gpu": CAPACITY, "global_batch": batch * world, "parallelism": f"dp{world}", "launch": launch},
@@ -188,8 +254,11 @@ def main():
             "kernel_ms": {k: round(v, 4) for k, v in sorted(avg_ms.items())},
             "losses": {k: round(v, 6) for k, v in losses.items()},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 3), "peak": PEAK_FP32_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_TFLOPS, 4), "traffic": measured_hbm_traffic(dom)},
+                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_TFLOPS, 4), "traffic": measured_hbm_traffic(dom),
+                         "mfma_busy": measured_mfma_busy(dom), "traffic_per_iteration": measured_iteration_traffic()},
         }
+        if forms:
+            out["update_forms"] = forms
         if exchange_ms:
             out["exchange_ms"] = {k: round(v, 4) for k, v in sorted(exchange_ms.items())}
         if world == 1 and not args.no_cpu_baseline:

@@ -12,6 +12,9 @@ import sqlite3
 import sys
 
 
+COUNTS = {}
+
+
 def per_kernel(db_path, counter):
     db = sqlite3.connect(db_path)
     cols = [d[0] for d in db.execute("select * from counters_collection limit 1").description]
@@ -22,6 +25,7 @@ def per_kernel(db_path, counter):
         m = re.search(r"(\w+_kernel)", name)
         if m:
             out[m.group(1)] = total / n
+            COUNTS[m.group(1)] = n
     return out
 
 
@@ -30,7 +34,16 @@ kernels = {}
 for k in sorted(set(fetch) & set(write)):
     kernels[k] = {"fetch_kb_per_launch": round(fetch[k], 1), "write_kb_per_launch": round(write[k], 1),
                   "hbm_bytes_per_launch": int(round((2.0 * fetch[k] + write[k]) * 1024))}
-print(json.dumps({"command": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- " + sys.argv[3],
+# one training iteration = the launches between two phase-1 row passes: every launch of the step kernels divided by the
+# number of iterations; the tail launch (rollout_eval_kernel) at its per-launch average, which the acting-only launches
+# that fill the ring pull down a little
+n_it = COUNTS.get("phase1_kernel", 0)
+iteration = None
+if n_it:
+    iteration = sum(kernels[k]["hbm_bytes_per_launch"] * COUNTS[k] / n_it for k in ("phase1_kernel", "phase2_kernel", "wpass_kernel", "apply_kernel")
+                    if k in kernels)
+    iteration = int(iteration + kernels.get("rollout_eval_kernel", {}).get("hbm_bytes_per_launch", 0))
+print(json.dumps({"iteration_hbm_bytes": iteration, "command": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- " + sys.argv[3],
                   "note": "per-launch averages over all dispatches of the run (for rollout_eval_kernel that includes the acting-only "
                           "launches that fill the ring); both counters are in KB; FETCH_SIZE is doubled (on gfx950 it tallies "
                           "128-byte requests at 64 bytes), WRITE_SIZE taken as is",
