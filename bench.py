@@ -164,8 +164,12 @@ def main():
     for _ in range(args.warmup):
         L.step()
 
+    # a one-rank job started through the launcher (RANK set) takes the multi-rank code paths below as well, which is how
+    # they are rehearsed on a single GPU (with RLGAN_FORCE_EXCHANGE=1 the all-reduces stay in the step too)
+    multi = dist.is_initialized()
+
     def barrier():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -177,7 +181,7 @@ def main():
             L.step()
         barrier()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if multi:
             t = torch.tensor([dt], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
@@ -187,7 +191,7 @@ def main():
         """A short region (--steps 20 is under 4 ms) cannot raise the clocks by itself and one host hiccup is a large
         share of it: besides the --warmup steps the loop first runs for a fixed 0.3 s, then the region of exactly
         `steps` steps is timed `repeats` times back to back and the MEDIAN region is the one reported."""
-        if world == 1:
+        if not multi:
             t_end = time.perf_counter() + 0.3
             while time.perf_counter() < t_end:
                 L.step()
@@ -204,7 +208,7 @@ def main():
 
     dt, dt_min, dt_max, repeats = measure(args.steps)
     forms = None
-    if world > 1 and launch == "graph":
+    if L.engine.exchange.enabled and launch == "graph":
         # the other form of the multi-rank update (two chains on two streams, one exchange per step), same run, same
         # measurement: the scaling record then shows which form the exchange latency favours
         try:
