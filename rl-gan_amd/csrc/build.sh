@@ -3,7 +3,7 @@
 set -euo pipefail
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -mllvm -amdgpu-mfma-vgpr-form=1"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -mllvm -amdgpu-mfma-vgpr-form=1 ${RLGAN_EXTRA_FLAGS:-}"   # RLGAN_EXTRA_FLAGS: experiments only (e.g. -DRLGAN_GD=3)
 mkdir -p build
 pids=()
 for f in learn_kernels rollout_kernels replay_kernels host_api conv_kernels dense_kernels deconv_kernels norm_kernels; do

@@ -41,9 +41,9 @@ __global__ __launch_bounds__(THREADS) void probe_kernel(const Args A) {
   }
 }
 
-int main() {
+int main() {  // PROBE_B: minibatch rows (4096 = one tile per compute unit, 8192 = two)
   Geo g; make_geo(NET_ACTOR, 7, 2, g);
-  const int B = 4096;
+  const int B = getenv("PROBE_B") ? atoi(getenv("PROBE_B")) : 4096;
   std::vector<float> wf(g.wf_floats), wb(g.wb_floats), s(B * 7);
   for (auto& v : wf) v = (rand() / (float)RAND_MAX - 0.5f) * 0.2f;
   for (auto& v : wb) v = (rand() / (float)RAND_MAX - 0.5f) * 0.2f;
