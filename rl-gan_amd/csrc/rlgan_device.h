@@ -208,31 +208,45 @@ struct FragSrc {
 // tiles w, w+4, w+8, ...  (NT%4 waves own one tile more than the others; with fewer than four tiles
 // some waves own none and only wait at the layer's barrier).  The rotation differs per workgroup so
 // that the busier waves of workgroups sharing a compute unit land on different SIMDs.
-// Pre holds the B operands of the first min(GD, NG) k-groups of this wave's tiles: issue() only starts
-// the loads; nothing waits until dense16 consumes them.
+// A wave walks its tiles ONE AFTER THE OTHER, each over the whole K range, so that the epilogue of a tile
+// (activation, LDS and global stores: vector-ALU and memory instructions) is issued between the MFMAs of
+// the next tile and costs no time of its own; only the last tile's epilogue is exposed.  The wave's work
+// is therefore a stream of steps, step s = k-group s % NG of its tile s / NG, and the B operands of the
+// steps are fetched through a ring of RING fragments, the refill for step s + DS requested at step s.
+// Pre holds the first DS fragments of the stream: issue() only starts the loads; nothing waits until
+// dense_tiles consumes them.
 // A wide layer with 4n+1 column tiles (13) would leave one wave a third more MFMAs than the others, and
 // the layer ends when that wave does.  There the last tile is SHARED instead: the other tiles are dealt
-// whole (three each), and of the last tile every wave computes the k-groups w, w+4, w+8, (w+12); the four
-// partial sums meet in LDS (`spart`, slot = rotated wave index, added in slot order) and all threads of
-// the workgroup apply the epilogue to that tile, one element each, behind one more barrier.
+// whole (three each), and of the last tile every wave computes the k-groups w, w+4, w+8, (w+12) as further
+// steps of its stream; the four partial sums meet in LDS (`spart`, slot = rotated wave index, added in slot
+// order) and all threads of the workgroup apply the epilogue to that tile, one element each, behind one more barrier.
+#ifndef RLGAN_RING
+#define RLGAN_RING 8
+#endif
+constexpr int RING = RLGAN_RING;
+
 template <int NT, int NG>
 struct Pre {
   static constexpr bool SPLIT = (NT % 4 == 1) && NT > 4 && NG >= 8;
   static constexpr int NTF = SPLIT ? NT - 1 : NT;      // tiles dealt whole
   static constexpr int NS = SPLIT ? (NG + 3) / 4 : 0;  // k-groups of the shared tile per wave (at most)
   static constexpr int TMAX = (NTF + 3) / 4, TMIN = NTF / 4, NHEAVY = NTF % 4;
-  static constexpr int D = NG < GD ? NG : GD;          // groups in flight
-  f32x4 b[D][TMAX];
+  static constexpr int SMIN = (TMIN > 0 ? TMIN : 1) * NG + NS;   // steps every working wave has
+  static constexpr int DS = SMIN < RING ? SMIN : RING;           // fragments in flight
+  f32x4 b[DS];
   FragSrc src;                                         // fragment blocks counted from this wave's tile 0, group 0
   int w;                                               // rotated wave index
 
+  // fragment block of step s of a wave that owns T whole tiles (steps at or beyond T*NG: the shared tile's k-groups)
+  template <int T>
+  __device__ __forceinline__ int block(int s) const {
+    if (s < T * NG) return (s % NG) * NT + 4 * (s / NG);
+    return min(w + 4 * (s - T * NG), NG - 1) * NT + (NT - 1) - w;
+  }
   template <int T>
   __device__ __forceinline__ void load_first() {
 #pragma unroll
-    for (int g = 0; g < D; ++g) {
-#pragma unroll
-      for (int i = 0; i < T; ++i) b[g][i] = src.load(g * NT + 4 * i);
-    }
+    for (int s = 0; s < DS; ++s) b[s] = src.load(block<T>(s));
   }
   __device__ __forceinline__ void issue(const float* __restrict__ wp) {
     w = (wave_id() + (int)blockIdx.x) & 3;
@@ -249,124 +263,123 @@ template <int KIND> using FwdPre = Pre<NT_H, first_groups(KIND)>;
 struct NoPre { __device__ __forceinline__ float operator()(int, int) const { return 0.f; } };
 struct NoNext { __device__ __forceinline__ void operator()() const {} };
 
-// The share of one wave in a dense layer: T column tiles over the whole K range.
-template <int NT, int NG, int T, class P, class F, class X>
-__device__ __forceinline__ void dense_tiles(Pre<NT, NG>& p, const float* xq, int r0, int c0, P pre, F f, float* gdst, X next,
-                                            float* spart) {
+// The share of one wave in a dense layer: T column tiles, each over the whole K range, one after the other.
+//   AREG: the layer has one k-group whose A operand (all 16 rows, the 16 k) the wave already holds in `areg`;
+//         otherwise the A operands come from LDS, one float4 at xq + 16*group.
+// Two accumulators per tile take the MFMAs in turn (a dependent MFMA would wait 40 cycles instead of 32).
+template <int NT, int NG, int T, bool AREG, class P, class F, class X>
+__device__ __forceinline__ void dense_tiles(Pre<NT, NG>& p, const float* xq, const f32x4 areg, int r0, int c0, P pre, F f,
+                                            float* gdst, X next, float* spart) {
   using Q = Pre<NT, NG>;
-  constexpr int D = Q::D;
-  constexpr int KC = (T == 1 && NG >= 4) ? 4 : 1;      // a lone tile splits K over independent accumulation chains
-  float hv[T][4];
+  static_assert(!AREG || NG == 1, "a register operand covers one k-group");
+  constexpr int DS = Q::DS, SW = T * NG, S = SW + Q::NS;
+  // epilogue of a finished tile, cut into pieces that are issued among the MFMAs of the steps that follow
+  constexpr int PIECES = (NG >= 7 || Q::NS >= 4) ? 6 : 1;
+  f32x4 ap0{0.f, 0.f, 0.f, 0.f}, ap1{0.f, 0.f, 0.f, 0.f}, zp{0.f, 0.f, 0.f, 0.f}, vp{0.f, 0.f, 0.f, 0.f};
+  float hvp[4] = {0.f, 0.f, 0.f, 0.f};
+  int colp = 0;
+  auto piece = [&](int k) {
+    // k = 0 .. PIECES-1 of the previous tile's epilogue; piece 0 adds the two accumulators (by then the tile's last
+    // MFMA has long left the pipe)
+    if (k == 0) zp = ap0 + ap1;
+    if constexpr (PIECES == 1) {
 #pragma unroll
-  for (int i = 0; i < T; ++i) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) hv[i][r] = pre(r0 + r, 16 * (p.w + 4 * i) + c0);
+      for (int r = 0; r < 4; ++r) vp[r] = f(r0 + r, colp, zp[r], hvp[r]);
+      if (gdst) *(f32x4*)(gdst + work_off(NT * 16, r0, colp)) = vp;
+    } else {
+      if (k >= 1 && k <= 4) vp[k - 1] = f(r0 + k - 1, colp, zp[k - 1], hvp[k - 1]);
+      if (k == 5 && gdst) *(f32x4*)(gdst + work_off(NT * 16, r0, colp)) = vp;
+    }
+  };
+  // A operands are read two steps ahead of their use (an LDS read takes about as long as four MFMAs)
+  auto a_at = [&](int s) {
+    return *(const f32x4*)(xq + 16 * (s < SW ? s % NG : min(p.w + 4 * (s - SW), NG - 1)));
+  };
+  f32x4 ar[3];
+  if constexpr (!AREG) {
+    ar[0] = a_at(0);
+    if (S > 1) ar[1] = a_at(1);
   }
-  f32x4 acc[T][KC];
-#pragma unroll
-  for (int i = 0; i < T; ++i) {
-#pragma unroll
-    for (int k = 0; k < KC; ++k) acc[i][k] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-  f32x4 am[D];
-#pragma unroll
-  for (int g = 0; g < D; ++g) am[g] = *(const f32x4*)(xq + 16 * g);
-  // this wave's k-groups of the shared tile: fragments requested now, used after the loop
-  f32x4 fs[Q::NS > 0 ? Q::NS : 1];
-  if constexpr (Q::SPLIT) {
-#pragma unroll
-    for (int j = 0; j < Q::NS; ++j) fs[j] = p.src.load(min(p.w + 4 * j, NG - 1) * NT + (NT - 1) - p.w);
-  }
+  f32x4 acc0{0.f, 0.f, 0.f, 0.f}, acc1{0.f, 0.f, 0.f, 0.f};
+  f32x4 s0{0.f, 0.f, 0.f, 0.f}, s1{0.f, 0.f, 0.f, 0.f};      // the shared tile's partial sums
+  float hv[4] = {0.f, 0.f, 0.f, 0.f};
   STAMP(2);
 #pragma unroll
-  for (int g = 0; g < NG; ++g) {
-    const int sl = g % D;
+  for (int s = 0; s < S; ++s) {
+    const bool whole = s < SW;
+    const int i = whole ? s / NG : T, g = whole ? s % NG : s - SW;
+    if (whole && g == 0) {
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-#pragma unroll
-      for (int i = 0; i < T; ++i)
-        acc[i][g % KC] = __builtin_amdgcn_mfma_f32_16x16x4f32(am[sl][m], p.b[sl][i][m], acc[i][g % KC], 0, 0, 0);
+      for (int r = 0; r < 4; ++r) hv[r] = pre(r0 + r, 16 * (p.w + 4 * i) + c0);
+      acc0 = f32x4{0.f, 0.f, 0.f, 0.f}; acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    if (g + D < NG) {
-#pragma unroll
-      for (int i = 0; i < T; ++i) p.b[sl][i] = p.src.load((g + D) * NT + 4 * i);
-      am[sl] = *(const f32x4*)(xq + 16 * (g + D));
+    if constexpr (!AREG) {
+      if (s + 2 < S) ar[(s + 2) % 3] = a_at(s + 2);
     }
-    // keep the refill D groups ahead of its use: the scheduler would otherwise sink these loads next
-    // to their consumers to save registers, and the wave would wait out a full L2 round trip per group
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  f32x4 sz{0.f, 0.f, 0.f, 0.f};
-  if constexpr (Q::SPLIT) {
-    f32x4 as[Q::NS], sacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-    for (int j = 0; j < Q::NS; ++j) as[j] = *(const f32x4*)(xq + 16 * min(p.w + 4 * j, NG - 1));
-#pragma unroll
-    for (int j = 0; j < Q::NS; ++j) {
-      if (4 * j + 3 < NG || p.w + 4 * j < NG) {        // only the last j depends on the wave
-#pragma unroll
-        for (int m = 0; m < 4; ++m) sacc[j & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(as[j][m], fs[j][m], sacc[j & 1], 0, 0, 0);
+    const f32x4 av = AREG ? areg : ar[s % 3];
+    const f32x4 bv = p.b[s % DS];
+    if (whole) {
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], bv[0], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], bv[1], acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], bv[2], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], bv[3], acc1, 0, 0, 0);
+    } else if (4 * g + 3 < NG || p.w + 4 * g < NG) {       // only the last k-group of the shared tile depends on the wave
+      s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], bv[0], s0, 0, 0, 0);
+      s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], bv[1], s1, 0, 0, 0);
+      s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], bv[2], s0, 0, 0, 0);
+      s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], bv[3], s1, 0, 0, 0);
+    }
+    if (s + DS < S) p.b[s % DS] = p.src.load(p.template block<T>(s + DS));
+    // epilogue pieces of the tile finished before this one
+    if (i > 0) {
+      if constexpr (PIECES == 1) {
+        if (g == 0) piece(0);
+      } else if (whole) {
+        // from the second step on: the first piece reads the accumulators, and the tile's last MFMA has left the
+        // pipe only a step after it was issued
+        if (g >= 1 && g <= PIECES) piece(g - 1);
+      } else {
+        // the steps of the shared tile take the six pieces: none, 0-2, 3-4, 5
+        if (g == 1) { piece(0); piece(1); piece(2); }
+        if (g == 2) { piece(3); piece(4); }
+        if (g == 3) piece(5);
       }
     }
-    sz = sacc[0] + sacc[1];
+    if (whole && g == NG - 1) {
+      // this tile is complete: hand it to the steps that follow
+      ap0 = acc0; ap1 = acc1; colp = 16 * (p.w + 4 * i) + c0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) hvp[r] = hv[r];
+    }
+    // keep the refill DS steps ahead of its use and the epilogue pieces inside their step: the scheduler would
+    // otherwise sink the loads next to their consumers to save registers, and the wave would wait out a full L2
+    // round trip per step
+    __builtin_amdgcn_sched_barrier(0);
   }
   STAMP(3);
   next();
-  __builtin_amdgcn_sched_barrier(0);   // the next layer's requests stay ahead of this layer's epilogue
+  __builtin_amdgcn_sched_barrier(0);   // the next layer's requests stay ahead of what is left of this layer's epilogue
   if constexpr (Q::SPLIT) {
+    static_assert(Q::NS >= 4, "the shared tile's steps carry the last whole tile's epilogue");
+    const f32x4 sz = s0 + s1;
     float* pw = spart + p.w * (ROWS * LDP) + r0 * LDP + c0;
 #pragma unroll
     for (int r = 0; r < 4; ++r) pw[r * LDP] = sz[r];
-  }
+  } else {
+    // the last tile's epilogue has nothing left to hide behind
 #pragma unroll
-  for (int i = 0; i < T; ++i) {
-    const int col = 16 * (p.w + 4 * i) + c0;
-    f32x4 z = acc[i][0];
-    if constexpr (KC == 4) z = ((acc[i][0] + acc[i][1]) + acc[i][2]) + acc[i][3];
-    f32x4 v;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = f(r0 + r, col, z[r], hv[i][r]);
-    if (gdst) *(f32x4*)(gdst + work_off(NT * 16, r0, col)) = v;
+    for (int k = 0; k < PIECES; ++k) piece(k);
   }
 }
 
-// A wave's tiles of a one-k-group layer whose A operand (all 16 rows, the 16 k of the group) the wave
-// already holds in registers.
-template <int NT, int T, class P, class F, class X>
-__device__ __forceinline__ void rega_tiles(Pre<NT, 1>& p, const f32x4 a, int r0, int c0, P pre, F f, float* gdst, X next) {
-  float hv[T][4];
-#pragma unroll
-  for (int i = 0; i < T; ++i) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) hv[i][r] = pre(r0 + r, 16 * (p.w + 4 * i) + c0);
-  }
-  f32x4 acc[T];
-#pragma unroll
-  for (int i = 0; i < T; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int m = 0; m < 4; ++m) {
-#pragma unroll
-    for (int i = 0; i < T; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], p.b[0][i][m], acc[i], 0, 0, 0);
-  }
-  next();
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int i = 0; i < T; ++i) {
-    const int col = 16 * (p.w + 4 * i) + c0;
-    f32x4 v;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = f(r0 + r, col, acc[i][r], hv[i][r]);
-    if (gdst) *(f32x4*)(gdst + work_off(NT * 16, r0, col)) = v;
-  }
-}
 template <int NT, class P, class F, class X>
 __device__ __forceinline__ void dense16_rega(Pre<NT, 1>& p, const f32x4 a, P pre, F f, float* gdst, X next) {
   using Q = Pre<NT, 1>;
   const int lane = threadIdx.x & 63;
   const int r0 = (lane >> 4) * 4, c0 = lane & 15;
-  if constexpr (Q::NHEAVY == 0) rega_tiles<NT, Q::TMAX>(p, a, r0, c0, pre, f, gdst, next);
-  else if (p.w < Q::NHEAVY) rega_tiles<NT, Q::TMAX>(p, a, r0, c0, pre, f, gdst, next);
-  else if constexpr (Q::TMIN > 0) rega_tiles<NT, Q::TMIN>(p, a, r0, c0, pre, f, gdst, next);
+  if constexpr (Q::NHEAVY == 0) dense_tiles<NT, 1, Q::TMAX, true>(p, nullptr, a, r0, c0, pre, f, gdst, next, nullptr);
+  else if (p.w < Q::NHEAVY) dense_tiles<NT, 1, Q::TMAX, true>(p, nullptr, a, r0, c0, pre, f, gdst, next, nullptr);
+  else if constexpr (Q::TMIN > 0) dense_tiles<NT, 1, Q::TMIN, true>(p, nullptr, a, r0, c0, pre, f, gdst, next, nullptr);
   else next();
   lds_barrier();
 }
@@ -468,15 +481,15 @@ __device__ __forceinline__ void dense16(Pre<NT, NG>& p, const float* xs, int ldx
   const float* xq = xs + c0 * ldx + r0;                 // A operands of a group: one float4 at xq + 16*group
   STAMP(1);
   if constexpr (Q::NHEAVY == 0) {
-    dense_tiles<NT, NG, Q::TMAX>(p, xq, r0, c0, pre, f, gdst, next, spart);
+    dense_tiles<NT, NG, Q::TMAX, false>(p, xq, f32x4{0.f, 0.f, 0.f, 0.f}, r0, c0, pre, f, gdst, next, spart);
     if constexpr (CH::active) chain.template run<Q::TMAX>(p.w, ys, ldy);
   } else {
     static_assert(!Q::SPLIT, "a shared tile leaves the whole tiles evenly dealt");
     if (p.w < Q::NHEAVY) {
-      dense_tiles<NT, NG, Q::TMAX>(p, xq, r0, c0, pre, f, gdst, next, spart);
+      dense_tiles<NT, NG, Q::TMAX, false>(p, xq, f32x4{0.f, 0.f, 0.f, 0.f}, r0, c0, pre, f, gdst, next, spart);
       if constexpr (CH::active) chain.template run<Q::TMAX>(p.w, ys, ldy);
     } else if constexpr (Q::TMIN > 0) {
-      dense_tiles<NT, NG, Q::TMIN>(p, xq, r0, c0, pre, f, gdst, next, spart);
+      dense_tiles<NT, NG, Q::TMIN, false>(p, xq, f32x4{0.f, 0.f, 0.f, 0.f}, r0, c0, pre, f, gdst, next, spart);
       if constexpr (CH::active) chain.template run<Q::TMIN>(p.w, ys, ldy);
     } else {
       next();

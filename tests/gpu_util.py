@@ -14,7 +14,7 @@ from rl_gan_amd.core import DeviceNet
 from rl_gan_amd.engine import ActorState, AdamState, CriticState, StepEngine
 from oracle import nets as onets
 from oracle.agent import CuriousAgent, Hyper
-from oracle_util import load_weights, make_batch, make_oracle  # noqa: F401
+from oracle_util import load_weights, make_batch, make_oracle, make_smooth_batch  # noqa: F401
 
 RTOL = 1e-5
 

@@ -54,3 +54,54 @@ def make_batch(B, seed=0, f32=True):
     if f32:
         b = b.astype(np.float32).astype(np.float64)
     return b
+
+
+# ---- minibatches without rows that sit on a kink -----------------------------------------------------------
+KINK_DELTA = 1e-6      # relative to the layer's largest |pre-activation|: ten float32 roundings of a 200-term sum
+
+
+def _near_kink_rows(spec, params, inputs, delta=KINK_DELTA):
+    """Rows with a pre-activation within delta * max|z| of a point where the layer's activation has a corner."""
+    _, cache = onets.forward(spec, params, inputs)
+    bad = np.zeros(cache["z"][0].shape[0], dtype=bool)
+    for kind, z in zip(spec.acts[:3], cache["z"][:3]):
+        lim = delta * np.abs(z).max()
+        if kind in ("relu", "relu6", "lrelu"):
+            bad |= (np.abs(z) < lim).any(axis=1)
+        if kind == "relu6":
+            bad |= (np.abs(z - 6.0) < lim).any(axis=1)
+    return bad
+
+
+def kink_rows(o, batch, delta=KINK_DELTA):
+    """Rows of a [B, 25] minibatch at which a backward pass of one of the four update steps (Curious_GAN.py:208-211),
+    each taken from the weights `o` holds now, meets a pre-activation within rounding of a corner of relu / relu6 /
+    leaky relu.  There the derivative is decided by the last bit of a float32 sum, so two correct float32
+    implementations (TensorFlow's included) may disagree by that row's whole contribution to the gradient, and a
+    float64 oracle cannot arbitrate.  (About 1.4 % of random rows; at batch 32,768 some row is on a corner in every
+    draw, and which ones trip depends on the order of additions inside the kernels.)"""
+    s, s_, g, a = batch[:, :7], batch[:, 7:14], batch[:, 14:21], batch[:, 21:23]
+    near = lambda spec, params, inputs: _near_kink_rows(spec, params, inputs, delta)
+    bad = near(o.critic_spec, o.critic_e, {"s": s, "a": a})                        # critic.learn
+    bad |= near(o.actor_spec, o.actor_e, {"s": s})                                  # ... the actor through it; actor.learn
+    bad |= near(o.critic_spec, o.critic_e, {"s": s, "a": o.choose_action(s)})       # actor.learn: live action
+    bad |= near(o.disc_spec, o.disc, {"s": s, "x": g, "a": a})                      # discriminator.learn: fake, real
+    bad |= near(o.disc_spec, o.disc, {"s": s, "x": s_, "a": a})
+    bad |= near(o.gen_spec, o.gen, {"s": s, "a": a})                                # generator.learn through D
+    bad |= near(o.disc_spec, o.disc, {"s": s, "x": o.predict(s, a), "a": a})
+    return bad
+
+
+def make_smooth_batch(o, B, seed=0, max_rounds=12):
+    """make_batch(B, seed) with the rows of `kink_rows` (for the weights `o` holds now) drawn again until none is left.
+    Returns the batch and the number of rows that were replaced."""
+    b = make_batch(B, seed)
+    replaced = 0
+    for k in range(max_rounds):
+        bad = kink_rows(o, b)
+        n = int(bad.sum())
+        if n == 0:
+            return b, replaced
+        b[bad] = make_batch(n, seed=seed * 1000 + 17 + k)
+        replaced += n
+    raise AssertionError("rows on a kink kept turning up")

@@ -12,7 +12,7 @@ def _fields(b):
     return dict(s=b[:, :7], s_=b[:, 7:14], g=b[:, 14:21], a=b[:, 21:23], r=b[:, 23:24], cr=b[:, 24:25])
 
 
-@pytest.mark.parametrize("B", [16, 32, 100, 4096, 32768])    # 32768: the global batch of the eight-GPU configuration on one GPU
+@pytest.mark.parametrize("B", [16, 32, 100, 4096])
 def test_each_step_gradients_losses_and_weights(B):
     from gpu_util import Pair, close, dev, make_batch
     p = Pair()
@@ -60,6 +60,45 @@ def test_each_step_gradients_losses_and_weights(B):
     out = eng.gan_eval(p.G, p.D, ft["g"], ft["s_"], ft["s"], ft["a"]).cpu().numpy()
     close(out[0], o.disc_eval(f["g"], f["s_"], f["s"], f["a"]), what="D_loss eval")
     close(out[1], o.gen_eval(f["s"], f["a"]), what="G_loss eval")
+
+
+def test_each_step_at_batch_32768():
+    """The global batch of the eight-GPU configuration on one GPU: every step from the SAME initial weights (four agents),
+    on a minibatch whose rows sit clear of the activations' corners for those weights.  Rows at which a backward pass meets
+    a pre-activation within float32 rounding of a corner of relu / relu6 / leaky relu are drawn again (about 1.4 % of
+    them): there the derivative mask hangs on the last bit of a float32 sum, a float64 oracle cannot say which side is
+    right, and in 32,768 rows some always are (oracle_util.kink_rows).  Steps chained through updated weights, as in
+    the test above, cannot be cleared this way: the weights a later step sees depend on the rows themselves."""
+    from gpu_util import Pair, close, dev, make_smooth_batch
+    B = 32768
+    p = Pair()
+    b, n_redrawn = make_smooth_batch(p.o, B, seed=B)
+    assert 0 < n_redrawn < B // 20
+    f, bt = _fields(b), dev(b)
+    ft = dict(s=bt[:, :7], s_=bt[:, 7:14], g=bt[:, 14:21], a=bt[:, 21:23], cr=bt[:, 24])
+    ref = p.o.critic_learn(f["s"], f["a"], f["cr"], f["s_"])
+    wc, wa = p.eng.critic_step(p.C, p.A, ft["s"], ft["a"], ft["cr"], ft["s_"])
+    close(wc.grad.cpu().numpy(), ref["g_critic"], what="critic grads")
+    close(wa.grad.cpu().numpy(), ref["g_actor"], what="actor grads through the critic loss")
+    close(p.eng.losses[p.eng.LOSS_CRITIC].item(), ref["loss"], what="TD loss")
+    p.check_weights("after critic step")
+    p = Pair()
+    ref = p.o.actor_learn(f["s"])
+    close(p.eng.actor_step(p.A, p.C, ft["s"]).grad.cpu().numpy(), ref["g_actor"], what="policy grads")
+    p.check_weights("after actor step")
+    p = Pair()
+    ref = p.o.disc_learn(f["g"], f["s_"], f["s"], f["a"])
+    close(p.eng.disc_step(p.D, ft["g"], ft["s_"], ft["s"], ft["a"]).grad.cpu().numpy(), ref["g_disc"], what="D grads")
+    close(p.eng.losses[p.eng.LOSS_D_STEP].item(), ref["loss"], what="D loss (pre-update)")
+    p.check_weights("after D step")
+    p = Pair()
+    ref = p.o.gen_learn(f["s"], f["a"])
+    close(p.eng.gen_step(p.G, p.D, ft["s"], ft["a"]).grad.cpu().numpy(), ref["g_gen"], what="G grads")
+    close(p.eng.losses[p.eng.LOSS_G_STEP].item(), ref["loss"], what="G loss (pre-update)")
+    p.check_weights("after G step")
+    out = p.eng.gan_eval(p.G, p.D, ft["g"], ft["s_"], ft["s"], ft["a"]).cpu().numpy()
+    close(out[0], p.o.disc_eval(f["g"], f["s_"], f["s"], f["a"]), what="D_loss eval")
+    close(out[1], p.o.gen_eval(f["s"], f["a"]), what="G_loss eval")
 
 
 @pytest.mark.parametrize("B", [32, 4096])
