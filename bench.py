@@ -12,7 +12,8 @@ fixed (weak scaling): every rank owns 4096 environments, a 2^20-row replay ring 
 minibatch; gradients are summed over ranks.  Data are synthetic (random-initialised networks,
 procedurally generated environments); all inputs are resident in HBM before the timed region.
 
-Rank 0 prints one JSON line.  `roofline` describes the dominant kernel (timed live with events on
+Rank 0 prints one JSON line.  `other_workloads` (one GPU only) holds the reference's two pixel configurations
+at the same batch, timed after the headline region and never part of `value`.  `roofline` describes the dominant kernel (timed live with events on
 the launch stream); `cpu_baseline` is the NumPy float32 restatement of the same update timed on the
 host cores of this box (a bounded sample).
 """
@@ -125,6 +126,8 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-workloads", action="store_true",
+                    help="skip the two pixel configurations timed after the headline workload (one GPU only)")
     ap.add_argument("--eager", action="store_true", help="launch kernels one by one instead of replaying a HIP graph")
     ap.add_argument("--strong", action="store_true",
                     help="strong scaling: 4096 environments and a global batch of 4096 split over the ranks (default: 4096 each per GPU)")
@@ -265,6 +268,14 @@ def main():
             out["update_forms"] = forms
         if exchange_ms:
             out["exchange_ms"] = {k: round(v, 4) for k, v in sorted(exchange_ms.items())}
+        if world == 1 and not multi and not args.no_other_workloads:
+            # the reference's two pixel configurations at the same batch, a couple of seconds each (tools/workloads.py);
+            # reported beside the headline, never part of `value`
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            from workloads import run_all
+            del L
+            torch.cuda.empty_cache()
+            out["other_workloads"] = run_all(BATCH)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         sys.stdout.flush()
