@@ -460,6 +460,28 @@ int rlgan_column_sums_noalloc(const float* dy, const float* y_relu, int64_t rows
 /* dst[i] = map[i] >= 0 ? src[map[i]] : 0   (a gradient image back into canonical parameter order) */
 int rlgan_gather_map(const float* src, const int32_t* map, int32_t n, float* dst, void* stream);
 
+/* ---- the same layers without the cols matrix in memory (dec_deconv3 and dec_deconv4, Conv_model.py:468-473) ----
+ * Two stride-2 shapes run as fused kernels: 8x8x64 -> 19x19x32 with a 5x5 kernel (kind 1) and 19x19x32 -> 42x42x1
+ * with a 6x6 kernel (kind 2); rlgan_deconv_fused_geometry reports kind 0 for every other shape, which keeps the
+ * cols form above.  The kernel is read from two fragment images filled from the canonical vector through
+ * rlgan_deconv_fused_build_maps + rlgan_pack_weights (or by rlgan_apply, map_f/wf and map_b/wb): wff for the
+ * forward pass, wfb for the input gradient; both must start as zeros (their padding is never written).
+ * Results: the values of the cols form up to the order of the float32 additions inside a product; taps are added
+ * in ascending (ky, kx) order in both forms, and every reduction has a fixed order (the same bits every run). */
+typedef struct { int32_t kind, wff_floats, wfb_floats, kernel_floats, max_chunks, bias_part_floats_per_image; } rlgan_deconv_fused_geom_t;
+int rlgan_deconv_fused_geometry(const rlgan_deconv_t* deconv, rlgan_deconv_fused_geom_t* out);
+/* floats of workspace rlgan_deconv_fused_backward needs for n_images (0: shape not fused) */
+int64_t rlgan_deconv_fused_workspace(const rlgan_deconv_t* deconv, int n_images);
+/* host arrays of n_params int32 each: offset of every canonical parameter in wff / wfb, -1 for the bias */
+int rlgan_deconv_fused_build_maps(const rlgan_deconv_t* deconv, int32_t* map_ff, int32_t* map_fb);
+/* y[n, oy, ox, co] = act(bias[co] + sum over taps and input channels), x = [n, h, w, c_in]; act_relu 0/1 */
+int rlgan_deconv_fused_forward(const rlgan_deconv_t* deconv, const float* x, const float* wff, const float* bias, float* y,
+                               int n_images, int act_relu, void* stream);
+/* grad = [kernel gradient in canonical order, bias gradient] of dZ = dy (* ReLU'(y_relu) when y_relu != NULL);
+ * dx (may be NULL) = input gradient [n, h, w, c_in].  workspace: rlgan_deconv_fused_workspace floats. */
+int rlgan_deconv_fused_backward(const rlgan_deconv_t* deconv, const float* x, const float* y_relu, const float* dy,
+                                const float* wfb, float* dx, float* workspace, float* grad, int n_images, void* stream);
+
 /* ---- glue of the pixel generator's training step (Conv_model.py:437-456,522-541) ------------------------
  * dz = dy * ReLU'(y)   (tf.nn.relu after the generator's first layer, Conv_model.py:455) */
 int rlgan_relu_backward(const float* dy, const float* y, float* dz, int64_t n, void* stream);

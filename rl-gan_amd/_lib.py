@@ -100,6 +100,10 @@ class DeconvGeom(C.Structure):
     _fields_ = [(n, _i32) for n in ("h_out", "w_out", "kk", "n_params", "wmat_floats", "colsum_floats")]
 
 
+class DeconvFusedGeom(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("kind", "wff_floats", "wfb_floats", "kernel_floats", "max_chunks", "bias_part_floats_per_image")]
+
+
 class Sample(C.Structure):
     _fields_ = [("mt_state", _fp), ("n_pop", C.c_int64), ("n", _i32), ("out_idx", _fp)]
 
@@ -177,6 +181,10 @@ PROTOTYPES = {
     "rlgan_deconv_build_map": [C.POINTER(Deconv), _vp],
     "rlgan_deconv_place": [C.POINTER(Deconv), _vp, _vp, _vp, _i, _i, _vp],
     "rlgan_deconv_gather": [C.POINTER(Deconv), _vp, _vp, _vp, _i, _vp],
+    "rlgan_deconv_fused_geometry": [C.POINTER(Deconv), C.POINTER(DeconvFusedGeom)],
+    "rlgan_deconv_fused_build_maps": [C.POINTER(Deconv), _vp, _vp],
+    "rlgan_deconv_fused_forward": [C.POINTER(Deconv), _vp, _vp, _vp, _vp, _i, _i, _vp],
+    "rlgan_deconv_fused_backward": [C.POINTER(Deconv), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "rlgan_column_sums": [_vp, _vp, C.c_int64, _i, _vp, _vp, _vp],
     "rlgan_column_sums_noalloc": [_vp, _vp, C.c_int64, _i, _vp, _vp],
     "rlgan_gather_map": [_vp, _vp, _i, _vp, _vp],
@@ -207,6 +215,8 @@ for _name, _args in PROTOTYPES.items():
     _fn = getattr(lib, _name)          # AttributeError here = the .so is older than this binding
     _fn.argtypes = _args
     _fn.restype = C.c_int
+lib.rlgan_deconv_fused_workspace.argtypes = [C.POINTER(Deconv), C.c_int]
+lib.rlgan_deconv_fused_workspace.restype = C.c_int64
 lib.rlgan_error_string.argtypes = [C.c_int]
 lib.rlgan_error_string.restype = C.c_char_p
 

@@ -1,0 +1,602 @@
+// Stride-2 transposed convolutions of the pixel generator's decoder (Conv_model.py:457-473) without the `cols`
+// matrix in memory, for the two layer shapes that carry most of the decoder's time:
+//
+//   tile layer    8x8x64  -> 19x19x32, 5x5 kernel (dec_deconv3, Conv_model.py:468): output channels in MFMA column
+//                 tiles; a wave owns one image and one 16-channel tile, multiplies the image's 64 input pixels with
+//                 one kernel tap at a time and adds the 64x16 result into its own copy of the output tile in LDS,
+//                 taps in ascending (ky, kx) order (no two waves ever touch the same output element);
+//   narrow layer  19x19x32 -> 42x42x1, 6x6 kernel (dec_deconv4, Conv_model.py:473): the 36 taps of the single
+//                 output channel are the MFMA columns; the per-image cols matrix (361 x 36) lives in LDS and the
+//                 placement gathers from there.
+//
+// Backward passes read the output gradient from LDS through the same pixel arithmetic: dX = sum over taps of
+// dZ[pixel(tap)] * W_tap^T, dW_tap = sum over images and pixels of dZ[pixel(tap)]^T * X, with per-chunk partial
+// kernels added in chunk order (the same bits every run).  Other shapes keep the cols form of deconv_kernels.hip.
+// gfx950 only.
+#include "rlgan_device.h"
+#include "rlgan_host.h"
+
+using namespace rlgan;
+
+namespace {
+
+inline int launched() { return (int)hipGetLastError(); }
+
+__device__ __forceinline__ float relu_d(float y) { return y > 0.f ? 1.f : 0.f; }
+__device__ __forceinline__ f32x4 mask4(f32x4 d, f32x4 y) {
+  return f32x4{d[0] * relu_d(y[0]), d[1] * relu_d(y[1]), d[2] * relu_d(y[2]), d[3] * relu_d(y[3])};
+}
+// orders the LDS traffic of one wave as written: a wave's LDS operations execute in program order, so a value
+// another lane of the same wave stored is visible to later reads as long as the compiler keeps that order
+__device__ __forceinline__ void keep_lds_order() { asm volatile("" ::: "memory"); }
+
+// ------------------------------------------------------------------------------------------------
+// tile layer
+// ------------------------------------------------------------------------------------------------
+template <int H_, int CI_, int CO_, int K_>
+struct TileT {
+  static constexpr int H = H_, CI = CI_, CO = CO_, K = K_;
+  static constexpr int P = H * H, MT = P / 16, KG = CI / 16, CT = CO / 16, NT = CI / 16, KGO = CO / 16;
+  static constexpr int HO = (H - 1) * 2 + K, NPIX = HO * HO, TAPS = K * K, KW = TAPS * CO * CI;
+  static constexpr int IPW = 4 / CT;                       // images per workgroup of the forward kernel
+  static_assert(P % 16 == 0 && CI % 16 == 0 && CO % 16 == 0 && 4 % CT == 0 && NT == 4, "tile layer shape");
+  static constexpr int FWD_LDS = 4 * NPIX * 16 * 4;        // four waves' output tiles [NPIX][16]
+  static constexpr int ZS = CO + 4;                        // pixel stride of the dZ image of the dX kernel
+  static constexpr int DX_LDS = (NPIX * ZS + 256) * 4;
+  // weight-gradient kernel: dZ rows oy = 2 iy + ky as [H][R], pixel stride S.  With H = 8 the four lane groups of
+  // an operand read (pixels 4 apart in x, or one input row apart) then start 16 banks apart.
+  static constexpr int S = CO + 2, R = ((HO * S + 31) / 64) * 64 + 32;
+  static constexpr int DW_LDS = (P * CI + H * R) * 4;
+  static constexpr int MAX_CHUNKS = 128;
+};
+using Mid = TileT<8, 64, 32, 5>;
+
+// y[n] = act(bias + sum over taps of place(X[n] W_tap)).  grid = ceil(n / IPW); wave = (image, channel tile).
+template <class T>
+__global__ __launch_bounds__(256) void deconv_tile_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wff,
+                                                               const float* __restrict__ bias, float* __restrict__ y,
+                                                               int n_images, int act) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lane = threadIdx.x & 63, wave = wave_id(), q = lane >> 4, j = lane & 15;
+  const int c = wave % T::CT, n = blockIdx.x * T::IPW + wave / T::CT;
+  if (n >= n_images) return;                               // the waves of this kernel never meet at a barrier
+  float* Y = lds + wave * (T::NPIX * 16);
+  FragSrc ws;
+  ws.set(wff, c * T::KG);
+  f32x4 b[2][T::KG];
+#pragma unroll
+  for (int g = 0; g < T::KG; ++g) b[0][g] = ws.load(g);
+  // the image's input pixels as A operands, kept for all taps
+  f32x4 a[T::MT][T::KG];
+  const float* xn = x + (size_t)n * T::P * T::CI;
+#pragma unroll
+  for (int t = 0; t < T::MT; ++t) {
+#pragma unroll
+    for (int g = 0; g < T::KG; ++g) a[t][g] = *(const f32x4*)(xn + (16 * t + j) * T::CI + 16 * g + 4 * q);
+  }
+  const f32x4 b4 = *(const f32x4*)(bias + 16 * c + 4 * (lane & 3));
+  for (int i = lane; i < T::NPIX * 4; i += 64) ((f32x4*)Y)[i] = b4;
+  keep_lds_order();
+  // LDS position of accumulator element (t, r) = input pixel 16 t + 4 q + r, channel j, for tap (0, 0)
+  int po[T::MT][4];
+#pragma unroll
+  for (int t = 0; t < T::MT; ++t) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int px = 16 * t + 4 * q + r;
+      po[t][r] = ((2 * (px / T::H)) * T::HO + 2 * (px % T::H)) * 16 + j;
+    }
+  }
+  f32x4 prev[T::MT];
+#pragma unroll
+  for (int tap = 0; tap <= T::TAPS; ++tap) {
+    f32x4 acc[T::MT];
+    if (tap < T::TAPS) {
+      if (tap + 1 < T::TAPS) {
+#pragma unroll
+        for (int g = 0; g < T::KG; ++g) b[(tap + 1) & 1][g] = ws.load((tap + 1) * T::CT * T::KG + g);
+      }
+#pragma unroll
+      for (int t = 0; t < T::MT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int g = 0; g < T::KG; ++g) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+#pragma unroll
+          for (int t = 0; t < T::MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][g][m], b[tap & 1][g][m], acc[t], 0, 0, 0);
+        }
+      }
+    }
+    if (tap > 0) {
+      // the previous tap's products go to their output pixels while this tap's MFMAs run
+      const int off = (((tap - 1) / T::K) * T::HO + (tap - 1) % T::K) * 16;
+#pragma unroll
+      for (int t = 0; t < T::MT; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Y[po[t][r] + off] += prev[t][r];
+      }
+      keep_lds_order();
+    }
+#pragma unroll
+    for (int t = 0; t < T::MT; ++t) prev[t] = acc[t];
+  }
+  float* yn = y + (size_t)n * T::NPIX * T::CO + 16 * c + 4 * (lane & 3);
+  for (int i = lane; i < T::NPIX * 4; i += 64) {
+    f32x4 v = ((const f32x4*)Y)[i];
+    if (act) v = f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+    *(f32x4*)(yn + (size_t)(i >> 2) * T::CO) = v;
+  }
+}
+
+// dX[n] = sum over taps of dZ[n][pixels of the tap] W_tap^T, dZ = dy * ReLU'(y); bias_part[n][co] = column sums of
+// dZ[n].  grid = n; wave = 16-wide tile of input channels.
+template <class T>
+__global__ __launch_bounds__(256) void deconv_tile_dx_kernel(const float* __restrict__ dy, const float* __restrict__ yact,
+                                                              const float* __restrict__ wfb, float* __restrict__ dx,
+                                                              float* __restrict__ bias_part) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* Z = lds;                                          // [NPIX][ZS]
+  float* red = lds + T::NPIX * T::ZS;                      // [256]
+  const int lane = threadIdx.x & 63, wave = wave_id(), q = lane >> 4, j = lane & 15;
+  const int n = blockIdx.x;
+  constexpr int STEPS = T::TAPS * T::KGO, RB = 4;
+  FragSrc ws;
+  ws.set(wfb, wave * STEPS);
+  f32x4 b[RB];
+#pragma unroll
+  for (int s = 0; s < RB; ++s) b[s] = ws.load(s);
+  constexpr int C4 = T::CO / 4;
+  const f32x4* dy4 = (const f32x4*)(dy + (size_t)n * T::NPIX * T::CO);
+  const f32x4* y4 = (const f32x4*)(yact + (size_t)n * T::NPIX * T::CO);
+  for (int i = threadIdx.x; i < T::NPIX * C4; i += 256) {
+    f32x4 d = dy4[i];
+    if (yact) d = mask4(d, y4[i]);
+    *(f32x4*)(Z + (i / C4) * T::ZS + 4 * (i % C4)) = d;
+  }
+  __syncthreads();
+  int ab[T::MT];
+#pragma unroll
+  for (int t = 0; t < T::MT; ++t) {
+    const int px = 16 * t + j;
+    ab[t] = ((2 * (px / T::H)) * T::HO + 2 * (px % T::H)) * T::ZS + 4 * q;
+  }
+  f32x4 acc[T::MT];
+#pragma unroll
+  for (int t = 0; t < T::MT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < STEPS; ++s) {
+    const int tap = s / T::KGO, g = s % T::KGO;
+    const int off = ((tap / T::K) * T::HO + tap % T::K) * T::ZS + 16 * g;
+    f32x4 av[T::MT];
+#pragma unroll
+    for (int t = 0; t < T::MT; ++t) av[t] = *(const f32x4*)(Z + ab[t] + off);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+#pragma unroll
+      for (int t = 0; t < T::MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t][m], b[s % RB][m], acc[t], 0, 0, 0);
+    }
+    if (s + RB < STEPS) b[s % RB] = ws.load(s + RB);
+  }
+  float* dxn = dx + (size_t)n * T::P * T::CI + 16 * wave + j;
+#pragma unroll
+  for (int t = 0; t < T::MT; ++t) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dxn[(16 * t + 4 * q + r) * T::CI] = acc[t][r];
+  }
+  // bias gradient of this image: thread = (pixel phase, channel), phases added in order
+  constexpr int PH = 256 / T::CO;
+  const int co = threadIdx.x % T::CO, ph = threadIdx.x / T::CO;
+  float s = 0.f;
+  for (int p = ph; p < T::NPIX; p += PH) s += Z[p * T::ZS + co];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x < T::CO) {
+    float tot = 0.f;
+#pragma unroll
+    for (int p = 0; p < PH; ++p) tot += red[p * T::CO + threadIdx.x];
+    bias_part[(size_t)n * T::CO + threadIdx.x] = tot;
+  }
+}
+
+// slabs[chunk][tap][co][ci] = sum over the chunk's images and input pixels of dZ[pixel(tap)][co] X[pixel][ci] for
+// the K taps of kernel row ky.  grid = (K, chunks); wave = 16-wide tile of input channels.
+template <class T>
+__global__ __launch_bounds__(256) void deconv_tile_dw_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                              const float* __restrict__ yact, float* __restrict__ slabs,
+                                                              int n_images, int per_chunk) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* Xt = lds;                                         // [P / 4][CI][4 pixels]
+  float* Zr = lds + T::P * T::CI;                          // [H][R], pixel stride S
+  const int lane = threadIdx.x & 63, wave = wave_id(), q = lane >> 4, j = lane & 15;
+  const int ky = blockIdx.x, chunk = blockIdx.y;
+  const int n0 = chunk * per_chunk, n1 = min(n_images, n0 + per_chunk);
+  f32x4 acc[T::K][T::CT];
+#pragma unroll
+  for (int kx = 0; kx < T::K; ++kx) {
+#pragma unroll
+    for (int c = 0; c < T::CT; ++c) acc[kx][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  constexpr int C4 = T::CO / 4;
+  for (int n = n0; n < n1; ++n) {
+    __syncthreads();                                       // the previous image's operands have been read
+    const float* xn = x + (size_t)n * T::P * T::CI;
+    for (int i = threadIdx.x; i < (T::P / 4) * T::CI; i += 256) {
+      const int pg = i / T::CI, ci = i % T::CI;
+      const float* xp = xn + (4 * pg) * T::CI + ci;
+      *(f32x4*)(Xt + i * 4) = f32x4{xp[0], xp[T::CI], xp[2 * T::CI], xp[3 * T::CI]};
+    }
+    for (int i = threadIdx.x; i < T::H * T::HO * C4; i += 256) {
+      const int iy = i / (T::HO * C4), rem = i % (T::HO * C4), ox = rem / C4, c4 = rem % C4;
+      const size_t at = (((size_t)n * T::HO + 2 * iy + ky) * T::HO + ox) * C4 + c4;
+      f32x4 d = ((const f32x4*)dy)[at];
+      if (yact) d = mask4(d, ((const f32x4*)yact)[at]);
+      float* z = Zr + iy * T::R + ox * T::S + 4 * c4;      // 8-byte aligned (S and R are even)
+      *(float2*)z = float2{d[0], d[1]};
+      *(float2*)(z + 2) = float2{d[2], d[3]};
+    }
+    __syncthreads();
+#pragma unroll
+    for (int G = 0; G < T::MT; ++G) {
+      const f32x4 bx = *(const f32x4*)(Xt + ((4 * G + q) * T::CI + 16 * wave + j) * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int px = 16 * G + 4 * q + e;
+        const float* zp = Zr + (px / T::H) * T::R + 2 * (px % T::H) * T::S + j;
+#pragma unroll
+        for (int kx = 0; kx < T::K; ++kx) {
+#pragma unroll
+          for (int c = 0; c < T::CT; ++c)
+            acc[kx][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(zp[kx * T::S + 16 * c], bx[e], acc[kx][c], 0, 0, 0);
+        }
+      }
+    }
+  }
+  float* out = slabs + (size_t)chunk * T::KW;
+#pragma unroll
+  for (int kx = 0; kx < T::K; ++kx) {
+#pragma unroll
+    for (int c = 0; c < T::CT; ++c) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        out[((ky * T::K + kx) * T::CO + 16 * c + 4 * q + r) * T::CI + 16 * wave + j] = acc[kx][c][r];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// narrow layer (one output channel)
+// ------------------------------------------------------------------------------------------------
+template <int H_, int CI_, int K_>
+struct NarrowT {
+  static constexpr int H = H_, CI = CI_, K = K_;
+  static constexpr int P = H * H, MT = (P + 15) / 16, PP = MT * 16, KG = CI / 16, NTC = CI / 16;
+  static constexpr int KK = K * K, NTN = (KK + 15) / 16, KS = KK / 4;      // taps as MFMA columns / as k-steps of 4
+  static constexpr int HO = (H - 1) * 2 + K, NO = HO * HO, KW = KK * CI;
+  static_assert(CI % 16 == 0 && KK % 4 == 0 && NTC == 2, "narrow layer shape");
+  static constexpr int CS = KK + 1;                                        // odd row stride of the cols matrix in LDS
+  static constexpr int FWD_LDS = P * CS * 4;
+  static constexpr int NTILES = NTN * NTC;                                 // weight-gradient tiles per wave
+  static constexpr int XT = PP * CI;                                       // transposed input [PP / 4][CI][4]
+  static_assert(4 * NTILES * 256 <= XT, "the cross-wave sum reuses the input's space");
+  static constexpr int BWD_LDS = (NO + XT + PP) * 4;
+  static constexpr int MAX_CHUNKS = 512;
+};
+using Last = NarrowT<19, 32, 6>;
+
+template <class N>
+__global__ __launch_bounds__(256) void deconv_narrow_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wff,
+                                                                 const float* __restrict__ bias, float* __restrict__ y, int act) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* cols = lds;                                       // [P][CS]
+  const int lane = threadIdx.x & 63, wave = wave_id(), q = lane >> 4, j = lane & 15;
+  const int n = blockIdx.x;
+  FragSrc ws;
+  ws.set(wff, 0);
+  f32x4 b[N::KG][N::NTN];
+#pragma unroll
+  for (int g = 0; g < N::KG; ++g) {
+#pragma unroll
+    for (int nt = 0; nt < N::NTN; ++nt) b[g][nt] = ws.load(g * N::NTN + nt);
+  }
+  const float* xn = x + (size_t)n * N::P * N::CI;
+  for (int t = wave; t < N::MT; t += 4) {
+    const int row = min(16 * t + j, N::P - 1);
+    f32x4 a[N::KG];
+#pragma unroll
+    for (int g = 0; g < N::KG; ++g) a[g] = *(const f32x4*)(xn + row * N::CI + 16 * g + 4 * q);
+#pragma unroll
+    for (int nt = 0; nt < N::NTN; ++nt) {
+      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int g = 0; g < N::KG; ++g) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[g][m], b[g][nt][m], acc, 0, 0, 0);
+      }
+      const int col = 16 * nt + j;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int px = 16 * t + 4 * q + r;
+        if (px < N::P && col < N::KK) cols[px * N::CS + col] = acc[r];
+      }
+    }
+  }
+  __syncthreads();
+  const float b0 = bias[0];
+  float* yn = y + (size_t)n * N::NO;
+  for (int o = threadIdx.x; o < N::NO; o += 256) {
+    const int oy = o / N::HO, ox = o % N::HO;
+    const int qy = oy >> 1, ry = oy & 1, qx = ox >> 1, rx = ox & 1;
+    float acc = b0;
+    for (int ky = ry, iy = qy; ky < N::K && iy >= 0; ky += 2, --iy) {      // ascending (ky, kx): the order of the cols form
+      if (iy >= N::H) continue;
+      for (int kx = rx, ix = qx; kx < N::K && ix >= 0; kx += 2, --ix) {
+        if (ix >= N::H) continue;
+        acc += cols[(iy * N::H + ix) * N::CS + ky * N::K + kx];
+      }
+    }
+    yn[o] = act ? fmaxf(acc, 0.f) : acc;
+  }
+}
+
+// dX[n][pixel][ci] = sum over taps of dZ[pixel(tap)] W[tap][ci] and slabs[chunk][tap][ci] = sum over the chunk's
+// images and pixels of dZ[pixel(tap)] X[pixel][ci].  grid = chunks; the 16-pixel tiles of an image go round the waves.
+template <class N, bool DX>
+__global__ __launch_bounds__(256) void deconv_narrow_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                 const float* __restrict__ yact, const float* __restrict__ wfb,
+                                                                 float* __restrict__ dx, float* __restrict__ slabs,
+                                                                 int n_images, int per_chunk) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* Dimg = lds;                                       // [NO] dZ of the image
+  float* Xt = lds + N::NO;                                 // [PP / 4][CI][4 pixels], zero beyond the image
+  int* pixtab = (int*)(lds + N::NO + N::XT);               // [PP] output pixel of tap (0, 0) per input pixel
+  const int lane = threadIdx.x & 63, wave = wave_id(), q = lane >> 4, j = lane & 15;
+  const int chunk = blockIdx.x;
+  const int n0 = chunk * per_chunk, n1 = min(n_images, n0 + per_chunk);
+  for (int p = threadIdx.x; p < N::PP; p += 256) {
+    const int px = min(p, N::P - 1);
+    pixtab[p] = (2 * (px / N::H)) * N::HO + 2 * (px % N::H);
+  }
+  int to[N::NTN], td[N::KS];
+#pragma unroll
+  for (int tt = 0; tt < N::NTN; ++tt) { const int tap = min(16 * tt + j, N::KK - 1); to[tt] = (tap / N::K) * N::HO + tap % N::K; }
+#pragma unroll
+  for (int e = 0; e < N::KS; ++e) { const int tap = 4 * e + q; td[e] = (tap / N::K) * N::HO + tap % N::K; }
+  float bw[N::KS][N::NTC];
+  if (DX) {
+#pragma unroll
+    for (int e = 0; e < N::KS; ++e) {
+#pragma unroll
+      for (int nt = 0; nt < N::NTC; ++nt) bw[e][nt] = wfb[(e * N::NTC + nt) * 64 + lane];
+    }
+  }
+  f32x4 accw[N::NTN][N::NTC];
+#pragma unroll
+  for (int tt = 0; tt < N::NTN; ++tt) {
+#pragma unroll
+    for (int nt = 0; nt < N::NTC; ++nt) accw[tt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  for (int n = n0; n < n1; ++n) {
+    __syncthreads();
+    const float* dyn = dy + (size_t)n * N::NO;
+    for (int o = threadIdx.x; o < N::NO; o += 256) {
+      float d = dyn[o];
+      if (yact) d *= relu_d(yact[(size_t)n * N::NO + o]);
+      Dimg[o] = d;
+    }
+    const float* xn = x + (size_t)n * N::P * N::CI;
+    for (int i = threadIdx.x; i < (N::PP / 4) * N::CI; i += 256) {
+      const int pg = i / N::CI, ci = i % N::CI;
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = 4 * pg + e < N::P ? xn[(4 * pg + e) * N::CI + ci] : 0.f;
+      *(f32x4*)(Xt + i * 4) = v;
+    }
+    __syncthreads();
+    for (int t = wave; t < N::MT; t += 4) {
+      if (DX) {
+        const int pb = pixtab[16 * t + j];
+        f32x4 accx[N::NTC];
+#pragma unroll
+        for (int nt = 0; nt < N::NTC; ++nt) accx[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < N::KS; ++e) {
+          const float av = Dimg[pb + td[e]];
+#pragma unroll
+          for (int nt = 0; nt < N::NTC; ++nt) accx[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw[e][nt], accx[nt], 0, 0, 0);
+        }
+        float* dxn = dx + (size_t)n * N::P * N::CI + j;
+#pragma unroll
+        for (int nt = 0; nt < N::NTC; ++nt) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int px = 16 * t + 4 * q + r;
+            if (px < N::P) dxn[px * N::CI + 16 * nt] = accx[nt][r];
+          }
+        }
+      }
+      const i32x4 pt = *(const i32x4*)(pixtab + 16 * t + 4 * q);
+      f32x4 bx[N::NTC];
+#pragma unroll
+      for (int nt = 0; nt < N::NTC; ++nt) bx[nt] = *(const f32x4*)(Xt + ((4 * t + q) * N::CI + 16 * nt + j) * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+#pragma unroll
+        for (int tt = 0; tt < N::NTN; ++tt) {
+          const float av = Dimg[pt[e] + to[tt]];
+#pragma unroll
+          for (int nt = 0; nt < N::NTC; ++nt) accw[tt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bx[nt][e], accw[tt][nt], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // the four waves' partial kernels, added in wave order
+  __syncthreads();
+  float* red = Xt;                                         // [4 waves][NTILES][64 lanes][4]
+#pragma unroll
+  for (int tt = 0; tt < N::NTN; ++tt) {
+#pragma unroll
+    for (int nt = 0; nt < N::NTC; ++nt) *(f32x4*)(red + ((wave * N::NTILES + tt * N::NTC + nt) * 64 + lane) * 4) = accw[tt][nt];
+  }
+  __syncthreads();
+  float* out = slabs + (size_t)chunk * N::KW;
+  for (int i = threadIdx.x; i < N::NTILES * 256; i += 256) {
+    const int tile = i >> 8, el = i & 255, ln = el >> 2, r = el & 3;
+    const int tt = tile / N::NTC, nt = tile % N::NTC;
+    const int tap = 16 * tt + 4 * (ln >> 4) + r, ci = 16 * nt + (ln & 15);
+    if (tap < N::KK) {
+      const float* p = red + tile * 256 + el;
+      out[tap * N::CI + ci] = ((p[0] + p[N::NTILES * 256]) + p[2 * N::NTILES * 256]) + p[3 * N::NTILES * 256];
+    }
+  }
+}
+
+// grad[p] = sum over chunks of slabs[chunk][p], chunks in order, eight loads in flight
+__global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ slabs, int n_chunks, int n, float* __restrict__ grad) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= n) return;
+  float tot = 0.f;
+  for (int c0 = 0; c0 < n_chunks; c0 += 8) {
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = c0 + i < n_chunks ? slabs[(size_t)(c0 + i) * n + p] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) tot += v[i];
+  }
+  grad[p] = tot;
+}
+
+enum { FUSED_NONE = 0, FUSED_TILE = 1, FUSED_NARROW = 2 };
+
+inline int fused_kind(const rlgan_deconv_t* d) {
+  if (!d || d->h != d->w || d->stride != 2) return FUSED_NONE;
+  if (d->h == Mid::H && d->c_in == Mid::CI && d->c_out == Mid::CO && d->k == Mid::K) return FUSED_TILE;
+  if (d->h == Last::H && d->c_in == Last::CI && d->c_out == 1 && d->k == Last::K) return FUSED_NARROW;
+  return FUSED_NONE;
+}
+
+inline void chunking(int n_images, int max_chunks, int* per_chunk, int* n_chunks) {
+  *per_chunk = (n_images + max_chunks - 1) / max_chunks;
+  *n_chunks = (n_images + *per_chunk - 1) / *per_chunk;
+}
+
+template <class KernelT>
+inline void allow_lds(KernelT k, int bytes) {
+  if (bytes > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
+}  // namespace
+
+extern "C" {
+
+int rlgan_deconv_fused_geometry(const rlgan_deconv_t* d, rlgan_deconv_fused_geom_t* out) {
+  if (!d || !out) return RLGAN_E_ARG;
+  const int kind = fused_kind(d);
+  out->kind = kind;
+  out->wff_floats = out->wfb_floats = out->kernel_floats = out->max_chunks = out->bias_part_floats_per_image = 0;
+  if (kind == FUSED_TILE) {
+    out->wff_floats = out->wfb_floats = out->kernel_floats = Mid::KW;
+    out->max_chunks = Mid::MAX_CHUNKS;
+    out->bias_part_floats_per_image = Mid::CO;
+  } else if (kind == FUSED_NARROW) {
+    out->wff_floats = Last::KG * Last::NTN * 256;
+    out->wfb_floats = Last::KS * Last::NTC * 64;
+    out->kernel_floats = Last::KW;
+    out->max_chunks = Last::MAX_CHUNKS;
+  }
+  return 0;
+}
+
+int64_t rlgan_deconv_fused_workspace(const rlgan_deconv_t* d, int n_images) {
+  const int kind = fused_kind(d);
+  if (kind == FUSED_NONE || n_images <= 0) return 0;
+  int per, nch;
+  if (kind == FUSED_TILE) {
+    chunking(n_images, Mid::MAX_CHUNKS, &per, &nch);
+    return (int64_t)nch * Mid::KW + (int64_t)n_images * Mid::CO + 512 * Mid::CO;
+  }
+  chunking(n_images, Last::MAX_CHUNKS, &per, &nch);
+  return (int64_t)nch * Last::KW + 512;
+}
+
+int rlgan_deconv_fused_build_maps(const rlgan_deconv_t* d, int32_t* map_ff, int32_t* map_fb) {
+  if (!d || !map_ff || !map_fb) return RLGAN_E_ARG;
+  const int kind = fused_kind(d);
+  if (kind == FUSED_NONE) return RLGAN_E_DIMS;
+  const int taps = d->k * d->k, CO = d->c_out, CI = d->c_in;
+  int p = 0;
+  for (int tap = 0; tap < taps; ++tap)
+    for (int co = 0; co < CO; ++co)
+      for (int ci = 0; ci < CI; ++ci, ++p) {
+        if (kind == FUSED_TILE) {
+          // forward: block (tap, channel tile, k-group of input channels); backward: block (input tile, tap, group of output channels)
+          map_ff[p] = (((tap * Mid::CT + co / 16) * Mid::KG + ci / 16) * 64 + 16 * ((ci % 16) / 4) + co % 16) * 4 + ci % 4;
+          map_fb[p] = ((((ci / 16) * Mid::TAPS + tap) * Mid::KGO + co / 16) * 64 + 16 * ((co % 16) / 4) + ci % 16) * 4 + co % 4;
+        } else {
+          map_ff[p] = frag_offset(Last::NTN, ci, tap);
+          map_fb[p] = ((tap / 4) * Last::NTC + ci / 16) * 64 + 16 * (tap % 4) + ci % 16;
+        }
+      }
+  for (int co = 0; co < CO; ++co, ++p) map_ff[p] = map_fb[p] = -1;      // the bias is read from the canonical vector
+  return 0;
+}
+
+int rlgan_deconv_fused_forward(const rlgan_deconv_t* d, const float* x, const float* wff, const float* bias, float* y,
+                               int n_images, int act_relu, void* stream) {
+  const int kind = fused_kind(d);
+  if (kind == FUSED_NONE) return RLGAN_E_DIMS;
+  if (!x || !wff || !bias || !y || n_images <= 0) return RLGAN_E_ARG;
+  if (((uintptr_t)x | (uintptr_t)wff | (uintptr_t)bias | (uintptr_t)y) & 15) return RLGAN_E_ALIGN;
+  if (kind == FUSED_TILE) {
+    allow_lds(deconv_tile_fwd_kernel<Mid>, Mid::FWD_LDS);
+    hipLaunchKernelGGL(deconv_tile_fwd_kernel<Mid>, dim3(cdiv(n_images, Mid::IPW)), dim3(256), Mid::FWD_LDS, (hipStream_t)stream,
+                       x, wff, bias, y, n_images, act_relu);
+  } else {
+    allow_lds(deconv_narrow_fwd_kernel<Last>, Last::FWD_LDS);
+    hipLaunchKernelGGL(deconv_narrow_fwd_kernel<Last>, dim3(n_images), dim3(256), Last::FWD_LDS, (hipStream_t)stream,
+                       x, wff, bias, y, act_relu);
+  }
+  return launched();
+}
+
+int rlgan_deconv_fused_backward(const rlgan_deconv_t* d, const float* x, const float* y_relu, const float* dy, const float* wfb,
+                                float* dx, float* workspace, float* grad, int n_images, void* stream) {
+  const int kind = fused_kind(d);
+  if (kind == FUSED_NONE) return RLGAN_E_DIMS;
+  if (!x || !dy || !wfb || !workspace || !grad || n_images <= 0) return RLGAN_E_ARG;
+  if (((uintptr_t)x | (uintptr_t)y_relu | (uintptr_t)dy | (uintptr_t)wfb | (uintptr_t)dx | (uintptr_t)workspace | (uintptr_t)grad) & 15)
+    return RLGAN_E_ALIGN;
+  hipStream_t st = (hipStream_t)stream;
+  int per, nch;
+  if (kind == FUSED_TILE) {
+    chunking(n_images, Mid::MAX_CHUNKS, &per, &nch);
+    float* slabs = workspace;
+    float* bias_part = slabs + (size_t)nch * Mid::KW;
+    float* colsum_scratch = bias_part + (size_t)n_images * Mid::CO;
+    hipLaunchKernelGGL(deconv_tile_dw_kernel<Mid>, dim3(Mid::K, nch), dim3(256), Mid::DW_LDS, st, x, dy, y_relu, slabs, n_images, per);
+    if (const int rc = launched()) return rc;
+    hipLaunchKernelGGL(slab_sum_kernel, dim3(cdiv(Mid::KW, 256)), dim3(256), 0, st, slabs, nch, Mid::KW, grad);
+    if (const int rc = launched()) return rc;
+    if (dx) {
+      hipLaunchKernelGGL(deconv_tile_dx_kernel<Mid>, dim3(n_images), dim3(256), Mid::DX_LDS, st, dy, y_relu, wfb, dx, bias_part);
+      if (const int rc = launched()) return rc;
+      return rlgan_column_sums(bias_part, nullptr, n_images, Mid::CO, colsum_scratch, grad + Mid::KW, stream);
+    }
+    return rlgan_column_sums(dy, y_relu, (int64_t)n_images * Mid::NPIX, Mid::CO, colsum_scratch, grad + Mid::KW, stream);
+  }
+  chunking(n_images, Last::MAX_CHUNKS, &per, &nch);
+  float* slabs = workspace;
+  float* colsum_scratch = slabs + (size_t)nch * Last::KW;
+  if (dx) {
+    hipLaunchKernelGGL((deconv_narrow_bwd_kernel<Last, true>), dim3(nch), dim3(256), Last::BWD_LDS, st, x, dy, y_relu, wfb, dx, slabs,
+                       n_images, per);
+  } else {
+    hipLaunchKernelGGL((deconv_narrow_bwd_kernel<Last, false>), dim3(nch), dim3(256), Last::BWD_LDS, st, x, dy, y_relu, wfb, dx, slabs,
+                       n_images, per);
+  }
+  if (const int rc = launched()) return rc;
+  hipLaunchKernelGGL(slab_sum_kernel, dim3(cdiv(Last::KW, 256)), dim3(256), 0, st, slabs, nch, Last::KW, grad);
+  if (const int rc = launched()) return rc;
+  return rlgan_column_sums(dy, y_relu, (int64_t)n_images * Last::NO, 1, colsum_scratch, grad + Last::KW, stream);
+}
+
+}  // extern "C"

@@ -23,7 +23,8 @@ class DeconvLayer:
     [k, k, c_out, c_in], then the bias."""
 
     def __init__(self, h: int, w: int, c_in: int, c_out: int, k: int, stride: int, rng: Optional[np.random.RandomState] = None,
-                 bias_init: float = 0.0, kernel: Optional[np.ndarray] = None, bias: Optional[np.ndarray] = None):
+                 bias_init: float = 0.0, kernel: Optional[np.ndarray] = None, bias: Optional[np.ndarray] = None, fused: bool = True):
+        """fused=False keeps the cols form for a shape that has a fused kernel (the two forms are compared in the tests)."""
         self.spec = _lib.Deconv(h, w, c_in, c_out, k, stride)
         self.geom = _lib.DeconvGeom()
         check(lib.rlgan_deconv_geometry(self.spec, C.byref(self.geom)), "rlgan_deconv_geometry")
@@ -43,6 +44,17 @@ class DeconvLayer:
         self.map_w = torch.from_numpy(m).to(dev)
         self.canon = torch.from_numpy(flat).to(dev)
         self.wmat = torch.zeros(g.wmat_floats, dtype=torch.float32, device=dev)     # [c_in + 1][kk], last row stays zero
+        # the two decoder shapes with fused kernels read the kernel from two fragment images instead of wmat
+        fg = _lib.DeconvFusedGeom()
+        check(lib.rlgan_deconv_fused_geometry(self.spec, C.byref(fg)), "rlgan_deconv_fused_geometry")
+        self.fused = fg.kind != 0 and fused
+        if self.fused:
+            mf, mb = np.empty(self.n_params, np.int32), np.empty(self.n_params, np.int32)
+            check(lib.rlgan_deconv_fused_build_maps(self.spec, mf.ctypes.data, mb.ctypes.data), "rlgan_deconv_fused_build_maps")
+            self.map_f, self.map_dx = torch.from_numpy(mf).to(dev), torch.from_numpy(mb).to(dev)
+            self.wfrag = torch.zeros(fg.wff_floats, dtype=torch.float32, device=dev)
+            self.wdx = torch.zeros(fg.wfb_floats, dtype=torch.float32, device=dev)
+            self._ws: Optional[torch.Tensor] = None
         self.grad = torch.zeros(self.n_params, dtype=torch.float32, device=dev)
         self._gmat = torch.empty(g.wmat_floats, dtype=torch.float32, device=dev)
         self._colsum = torch.empty(max(1, g.colsum_floats), dtype=torch.float32, device=dev)
@@ -51,6 +63,10 @@ class DeconvLayer:
         self.pack()
 
     def pack(self) -> None:
+        if self.fused:
+            check(lib.rlgan_pack_weights(self.canon.data_ptr(), self.kk * self.c_in, self.map_f.data_ptr(), self.wfrag.data_ptr(),
+                                         self.map_dx.data_ptr(), self.wdx.data_ptr(), _stream()), "rlgan_pack_weights")
+            return
         check(lib.rlgan_pack_weights(self.canon.data_ptr(), self.kk * self.c_in, self.map_w.data_ptr(), self.wmat.data_ptr(), None, None,
                                      _stream()), "rlgan_pack_weights")
 
@@ -80,6 +96,11 @@ class DeconvLayer:
     def forward(self, x: torch.Tensor, act: bool = True) -> torch.Tensor:
         n = x.shape[0]
         assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and tuple(x.shape[1:]) == (self.h, self.w, self.c_in)
+        if self.fused:
+            y = torch.empty((n, self.h_out, self.w_out, self.c_out), dtype=torch.float32, device=x.device)
+            check(lib.rlgan_deconv_fused_forward(self.spec, x.data_ptr(), self.wfrag.data_ptr(), self.bias.data_ptr(), y.data_ptr(), n,
+                                                 1 if act else 0, _stream()), "rlgan_deconv_fused_forward")
+            return y
         rows = n * self.h * self.w
         cols = self._cols_buffer(rows)
         sc, ns = self._slabs(rows, self.kk, self.c_in + 1)
@@ -95,6 +116,15 @@ class DeconvLayer:
         n = x.shape[0]
         rows = n * self.h * self.w
         yr = y.data_ptr() if act else None
+        if self.fused:
+            need = lib.rlgan_deconv_fused_workspace(self.spec, n)
+            if self._ws is None or self._ws.numel() < need:
+                self._ws = torch.empty(need, dtype=torch.float32, device=x.device)
+            dx = torch.empty_like(x) if need_dx else None
+            check(lib.rlgan_deconv_fused_backward(self.spec, x.data_ptr(), yr, dy.data_ptr(), self.wdx.data_ptr(),
+                                                  None if dx is None else dx.data_ptr(), self._ws.data_ptr(), self.grad.data_ptr(), n,
+                                                  _stream()), "rlgan_deconv_fused_backward")
+            return dx
         dcols = self._cols_buffer(rows)
         check(lib.rlgan_deconv_gather(self.spec, dy.data_ptr(), yr, dcols.data_ptr(), n, _stream()), "rlgan_deconv_gather")
         sc, ns = self._slabs(self.c_in + 1, self.kk, rows)

@@ -81,7 +81,7 @@ class PixelGenerator:
         self.decoder = Decoder(N_L1, rng=rng, params=decoder_params)
         self.obs_encoder = obs_encoder
         self.step = torch.zeros(1, dtype=torch.int32, device=device())
-        self._opt: List[_Adam] = [_Adam(self.l1)] + [_Adam(L, L.map_w, L.wmat) for L in self.decoder.layers]
+        self._opt: List[_Adam] = [_Adam(self.l1)] + [_adam_for(L) for L in self.decoder.layers]
         self._x = self._h1 = self._img = None
         self._parts: Optional[torch.Tensor] = None
         self.loss_out = torch.zeros(1, dtype=torch.float32, device=device())

@@ -10,7 +10,11 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("h,ci,co,k,s,act,n", [(1, 200, 128, 3, 2, True, 5), (3, 128, 64, 4, 2, True, 3), (8, 64, 32, 5, 2, True, 4),
-                                                (19, 32, 1, 6, 2, False, 3), (4, 8, 6, 2, 3, True, 2)])
+                                                (19, 32, 1, 6, 2, False, 3), (4, 8, 6, 2, 3, True, 2),
+                                                # the two shapes with fused kernels: odd and larger image counts (two images per
+                                                # workgroup forward, chunks of images backward), with and without ReLU
+                                                (8, 64, 32, 5, 2, True, 1), (8, 64, 32, 5, 2, False, 7), (8, 64, 32, 5, 2, True, 150),
+                                                (19, 32, 1, 6, 2, True, 1), (19, 32, 1, 6, 2, False, 70)])
 def test_layer_forward_and_backward(h, ci, co, k, s, act, n):
     import rl_gan_amd as R
     from gpu_util import close
@@ -38,6 +42,17 @@ def test_layer_forward_and_backward(h, ci, co, k, s, act, n):
     y2 = L.forward(xt, act=act)
     L.backward(xt, y2, torch.from_numpy(dy.astype(np.float32)).cuda(), act=act)
     assert torch.equal(y2, yt) and torch.equal(L.grad, g1)
+    # without the input gradient the parameter gradients are the same
+    assert L.backward(xt, yt, torch.from_numpy(dy.astype(np.float32)).cuda(), need_dx=False, act=act) is None
+    close(L.grad.cpu().numpy(), g1.cpu().numpy(), what="grad without dx")
+    if L.fused:
+        # the cols form of the same layer agrees to rounding
+        L2 = R.DeconvLayer(h, h, ci, co, k, s, kernel=w, bias=b, fused=False)
+        assert not L2.fused
+        y3 = L2.forward(xt, act=act)
+        close(yt.cpu().numpy(), y3.cpu().numpy().astype(np.float64), what="y, fused against cols")
+        dx3 = L2.backward(xt, y3, torch.from_numpy(dy.astype(np.float32)).cuda(), act=act)
+        close(dxt.cpu().numpy(), dx3.cpu().numpy().astype(np.float64), what="dx, fused against cols")
 
 
 def test_decoder_end_to_end():

@@ -28,7 +28,7 @@ def test_every_declared_symbol_is_exported_and_bound():
     assert len(names) >= 29
     for n in names:
         assert hasattr(_lib.lib, n), f"{n} is declared in include/rlgan_amd.h but not exported by the library"
-    bound = set(_lib.PROTOTYPES) | {"rlgan_error_string"}
+    bound = set(_lib.PROTOTYPES) | {"rlgan_error_string", "rlgan_deconv_fused_workspace"}     # the two that do not return int
     assert set(names) == bound, (set(names) ^ bound)
 
 
@@ -155,6 +155,33 @@ def test_batchnorm_chunks_cover_the_rows():
         ch = f(m)
         rows = max(32, -(-m // 128))
         assert 1 < ch <= 128 and ch == -(-m // rows) and rows * ch >= m > rows * (ch - 1)
+
+
+@pytest.mark.parametrize("shape,kind", [((8, 8, 64, 32, 5, 2), 1), ((19, 19, 32, 1, 6, 2), 2), ((3, 3, 128, 64, 4, 2), 0),
+                                        ((8, 8, 64, 32, 5, 1), 0), ((8, 8, 64, 16, 5, 2), 0)])
+def test_fused_decoder_layer_shapes_and_maps(shape, kind):
+    """dec_deconv3 and dec_deconv4 (Conv_model.py:468-473) have fused kernels; their two fragment images take every kernel
+    element exactly once and leave the bias out; any other shape reports kind 0 and needs no workspace."""
+    d = _lib.Deconv(*shape)
+    g = _lib.DeconvFusedGeom()
+    assert _lib.lib.rlgan_deconv_fused_geometry(d, C.byref(g)) == 0 and g.kind == kind
+    h, _, ci, co, k, _ = shape
+    n = k * k * co * ci
+    mf, mb = np.full(n + co, -7, np.int32), np.full(n + co, -7, np.int32)
+    if kind == 0:
+        assert _lib.lib.rlgan_deconv_fused_workspace(d, 64) == 0
+        assert _lib.lib.rlgan_deconv_fused_build_maps(d, mf.ctypes.data, mb.ctypes.data) == -2
+        assert _lib.lib.rlgan_deconv_fused_forward(d, 256, 256, 256, 256, 4, 1, None) == -2
+        return
+    assert g.kernel_floats == n
+    _lib.check(_lib.lib.rlgan_deconv_fused_build_maps(d, mf.ctypes.data, mb.ctypes.data))
+    for m, size in ((mf, g.wff_floats), (mb, g.wfb_floats)):
+        assert np.all(m[n:] == -1) and m[:n].min() >= 0 and m[:n].max() < size and np.unique(m[:n]).size == n
+    chunks = min(g.max_chunks, 100)
+    assert _lib.lib.rlgan_deconv_fused_workspace(d, 100) >= chunks * n
+    assert _lib.lib.rlgan_deconv_fused_forward(d, None, 256, 256, 256, 4, 1, None) == -1
+    assert _lib.lib.rlgan_deconv_fused_forward(d, 256, 256, 260, 256, 4, 1, None) == -5               # 16-byte alignment
+    assert _lib.lib.rlgan_deconv_fused_backward(d, 256, None, 256, 256, None, None, 256, 4, None) == -1   # workspace missing
 
 
 def test_argument_errors_of_the_pixel_entry_points():
