@@ -395,8 +395,10 @@ int rlgan_elu_backward(const float* dy, const float* y, float* dz, int64_t n, vo
 /* dx[n, h, w, c_in] from dz[n, h_out, w_out, c_out].  With wdx (see rlgan_conv_build_dx_map): one
  * implicit GEMM per stride phase on the matrix cores; with wdx NULL: a gather from the canonical kernel
  * w_canon (device, [k*k*c_in, c_out]) on the vector ALUs, for layers wdx does not cover.
- * y_elu (optional, needs wdx): the layer's output; `dz` is then dy and is multiplied by ELU'(y) as it is
- * read, which saves the separate rlgan_elu_backward pass. */
+ * A layer with c_in == 4 (an encoder's first layer) and w_canon given runs a kernel of its own instead, one
+ * thread per input pixel, whatever wdx is.
+ * y_elu (optional, needs wdx or c_in == 4): the layer's output; `dz` is then dy and is multiplied by ELU'(y)
+ * as it is read, which saves the separate rlgan_elu_backward pass. */
 int rlgan_conv_backward_input(const rlgan_conv_t* conv, const float* dz, const float* y_elu, const float* w_canon, const float* wdx,
                               float* dx, int n_images, void* stream);
 /* grad (canonical order, kernel then bias) = sum over all output pixels.  `slabs`: device scratch of

@@ -124,7 +124,7 @@ class ConvLayer:
         n = x.shape[0]
         use_mfma = self.wdx is not None and not self.gather_dx
         # ELU' is applied by the consumers as they read dy (no pass of its own) unless the gather kernel runs
-        fuse = act and (use_mfma or not need_dx)
+        fuse = act and (use_mfma or self.c_in == 4 or not need_dx)     # four input channels: a kernel of its own, ELU' included
         dz, yel = dy, (y.data_ptr() if fuse else None)
         if act and not fuse:
             dz = torch.empty_like(dy)

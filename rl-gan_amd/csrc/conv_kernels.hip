@@ -287,6 +287,131 @@ __device__ __forceinline__ f32x4 dz_value(const DzRaw& r) {
               : f32x4{0.f, 0.f, 0.f, 0.f};
 }
 
+// Input gradient of a layer with FOUR input channels (the first layer of an encoder: a frame stack, or one frame
+// padded to four channels): far too narrow for a matrix tile, and bound by reading dZ.  A thread owns one input
+// pixel; blockIdx.y = stride phase (y % s, x % s), so the taps a workgroup sees and their kernel rows are the same
+// for all its threads (the weights come through scalar loads) and neighbouring threads read neighbouring dZ rows,
+// 16 bytes at a time.  Taps in ascending (ky, kx) order, output channels in ascending order.
+struct C4Off { FastDiv dper[16], dnb[16]; int na[16], nb[16]; };
+// CO > 0: the layer's output channels as a compile-time constant (loops unrolled, kernel rows fetched by a few wide
+// scalar loads per tap); CO == 0: any width.
+template <int CO>
+__global__ __launch_bounds__(256) void conv_dx_c4_kernel(const ConvG g, const C4Off o, const float* __restrict__ dz,
+                                                         const float* __restrict__ yelu, const float* __restrict__ w /*[K][Cout]*/,
+                                                         float* __restrict__ dx, int n_images) {
+  const int cout = CO > 0 ? CO : g.Cout;
+  const int ph = blockIdx.y, ry = ph / g.s, rx = ph % g.s;
+  const int per = o.na[ph] * o.nb[ph];
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= n_images * per) return;                      // the host checked that the product fits an int
+  const int b = fdiv(t, o.dper[ph]), r = t - b * per, qy = fdiv(r, o.dnb[ph]), qx = r - qy * o.nb[ph];
+  f32x4 acc{0.f, 0.f, 0.f, 0.f};
+  for (int ky = ry, jy = 0; ky < g.k; ky += g.s, ++jy) {
+    const int oy = qy - jy;
+    for (int kx = rx, jx = 0; kx < g.k; kx += g.s, ++jx) {
+      const int ox = qx - jx;
+      const bool ok = oy >= 0 && oy < g.Ho && ox >= 0 && ox < g.Wo;
+      const size_t at = (((size_t)b * g.Ho + (ok ? oy : 0)) * g.Wo + (ok ? ox : 0)) * cout;
+      const float* wp = w + (size_t)((ky * g.k + kx) * 4) * cout;
+      if constexpr (CO > 0) {
+        f32x4 z[CO / 4];
+#pragma unroll
+        for (int i = 0; i < CO / 4; ++i) z[i] = *(const f32x4*)(dz + at + 4 * i);
+        if (yelu) {
+#pragma unroll
+          for (int i = 0; i < CO / 4; ++i) {
+            const f32x4 y = *(const f32x4*)(yelu + at + 4 * i);
+            z[i] = f32x4{z[i][0] * elu_d(y[0]), z[i][1] * elu_d(y[1]), z[i][2] * elu_d(y[2]), z[i][3] * elu_d(y[3])};
+          }
+        }
+        const float keep = ok ? 1.f : 0.f;
+        f32x4 part{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+          for (int i = 0; i < CO / 4; ++i) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) part[c] += z[i][m] * wp[c * CO + 4 * i + m];
+          }
+        }
+        acc += part * keep;
+      } else {
+        for (int n = 0; n < cout; n += 4) {
+          f32x4 z = *(const f32x4*)(dz + at + n);
+          if (yelu) {
+            const f32x4 y = *(const f32x4*)(yelu + at + n);
+            z = f32x4{z[0] * elu_d(y[0]), z[1] * elu_d(y[1]), z[2] * elu_d(y[2]), z[3] * elu_d(y[3])};
+          }
+          if (!ok) z = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[c] += z[m] * wp[c * cout + n + m];
+          }
+        }
+      }
+    }
+  }
+  const int yy = qy * g.s + ry, xx = qx * g.s + rx;
+  *(f32x4*)(dx + (((size_t)b * g.H + yy) * g.W + xx) * 4) = acc;
+}
+
+// The same for a layer whose whole dZ image fits LDS: a workgroup owns one image, multiplies dZ by ELU' once while
+// staging it (pixel stride CO + 1 floats: neighbouring pixels start on neighbouring banks) and walks the stride phases
+// one after the other, so that the taps stay uniform inside a wave.  dZ is read from memory once instead of once per
+// tap that touches it.
+template <int CO>
+__global__ __launch_bounds__(256) void conv_dx_c4_lds_kernel(const ConvG g, const C4Off o, const float* __restrict__ dz,
+                                                             const float* __restrict__ yelu, const float* __restrict__ w,
+                                                             float* __restrict__ dx) {
+  extern __shared__ __attribute__((aligned(16))) float Z[];      // [Ho * Wo][CO + 1]
+  constexpr int C4 = CO / 4, ZS = CO + 1;
+  const int n = blockIdx.x, npix = g.Ho * g.Wo;
+  const f32x4* dz4 = (const f32x4*)(dz + (size_t)n * npix * CO);
+  const f32x4* y4 = (const f32x4*)(yelu + (size_t)n * npix * CO);
+  for (int i = threadIdx.x; i < npix * C4; i += 256) {
+    f32x4 z = dz4[i];
+    if (yelu) {
+      const f32x4 y = y4[i];
+      z = f32x4{z[0] * elu_d(y[0]), z[1] * elu_d(y[1]), z[2] * elu_d(y[2]), z[3] * elu_d(y[3])};
+    }
+    float* zp = Z + (i / C4) * ZS + 4 * (i % C4);
+    zp[0] = z[0]; zp[1] = z[1]; zp[2] = z[2]; zp[3] = z[3];
+  }
+  __syncthreads();
+  float* dxn = dx + (size_t)n * g.H * g.W * 4;
+  for (int ph = 0; ph < g.s * g.s; ++ph) {
+    const int ry = ph / g.s, rx = ph % g.s, per = o.na[ph] * o.nb[ph];
+    for (int i = threadIdx.x; i < per; i += 256) {
+      const int qy = fdiv(i, o.dnb[ph]), qx = i - qy * o.nb[ph];
+      f32x4 acc{0.f, 0.f, 0.f, 0.f};
+      for (int ky = ry, jy = 0; ky < g.k; ky += g.s, ++jy) {
+        const int oy = qy - jy;
+        for (int kx = rx, jx = 0; kx < g.k; kx += g.s, ++jx) {
+          const int ox = qx - jx;
+          const bool ok = oy >= 0 && oy < g.Ho && ox >= 0 && ox < g.Wo;
+          const float* zp = Z + ((ok ? oy : 0) * g.Wo + (ok ? ox : 0)) * ZS;
+          const float* wp = w + (size_t)((ky * g.k + kx) * 4) * CO;
+          f32x4 part{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int c0 = 0; c0 < CO; c0 += 8) {
+            float z[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) z[e] = zp[c0 + e];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) part[c] += z[e] * wp[c * CO + c0 + e];
+            }
+          }
+          acc += part * (ok ? 1.f : 0.f);
+        }
+      }
+      *(f32x4*)(dxn + ((size_t)(qy * g.s + ry) * g.W + qx * g.s + rx) * 4) = acc;
+    }
+  }
+}
+
 // One wave = 16 input pixels of one class x all Cin column tiles; blockIdx.y = class.  The class's kernel
 // fragment is the row operand and the gathered dZ row the column operand: a lane ends up with four consecutive
 // input channels of one pixel, its own, and writes them as one 16-byte store.
@@ -768,7 +893,31 @@ int rlgan_conv_backward_input(const rlgan_conv_t* conv, const float* dz, const f
                               float* dx, int n_images, void* stream) {
   ConvG g;
   if (!make_conv(conv, g)) return RLGAN_E_DIMS;
-  if (!dz || (!w_canon && !wdx) || !dx || n_images <= 0 || (y_elu && !wdx)) return RLGAN_E_ARG;
+  if (!dz || (!w_canon && !wdx) || !dx || n_images <= 0) return RLGAN_E_ARG;
+  if (g.Cin == 4 && w_canon && g.s <= 4) {
+    C4Off o;
+    int most = 0;
+    for (int ph = 0; ph < g.s * g.s; ++ph) {
+      o.na[ph] = (g.H - ph / g.s + g.s - 1) / g.s; o.nb[ph] = (g.W - ph % g.s + g.s - 1) / g.s;
+      o.dper[ph] = make_div(o.na[ph] * o.nb[ph]); o.dnb[ph] = make_div(o.nb[ph]);
+      most = std::max(most, o.na[ph] * o.nb[ph]);
+    }
+    if ((long long)n_images * most > 0x7fffffffll || (((uintptr_t)dx | (uintptr_t)dz | (uintptr_t)y_elu) & 15)) return RLGAN_E_ALIGN;
+    const dim3 grid((unsigned)cdiv(n_images * most, 256), g.s * g.s), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t zlds = (size_t)g.Ho * g.Wo * (g.Cout + 1) * sizeof(float);
+    if ((g.Cout == 32 || g.Cout == 8) && zlds <= 64 * 1024) {
+      const dim3 gi(n_images);
+      if (g.Cout == 32) hipLaunchKernelGGL(conv_dx_c4_lds_kernel<32>, gi, block, zlds, st, g, o, dz, y_elu, w_canon, dx);
+      else hipLaunchKernelGGL(conv_dx_c4_lds_kernel<8>, gi, block, zlds, st, g, o, dz, y_elu, w_canon, dx);
+      return launched();
+    }
+    if (g.Cout == 32) hipLaunchKernelGGL(conv_dx_c4_kernel<32>, grid, block, 0, st, g, o, dz, y_elu, w_canon, dx, n_images);
+    else if (g.Cout == 8) hipLaunchKernelGGL(conv_dx_c4_kernel<8>, grid, block, 0, st, g, o, dz, y_elu, w_canon, dx, n_images);
+    else hipLaunchKernelGGL(conv_dx_c4_kernel<0>, grid, block, 0, st, g, o, dz, y_elu, w_canon, dx, n_images);
+    return launched();
+  }
+  if (y_elu && !wdx) return RLGAN_E_ARG;
   if (wdx) {
     DxOff offs;
     if (dx_layout(g, &offs) == 0) return RLGAN_E_DIMS;

@@ -115,7 +115,9 @@ def test_dense_argument_errors():
 @pytest.mark.parametrize("h,cin,cout,k,st", [(84, 4, 8, 5, 4), (41, 32, 32, 3, 2), (9, 16, 32, 3, 2), (12, 8, 16, 3, 3), (10, 4, 4, 2, 4)])
 def test_input_gradient_two_ways(h, cin, cout, k, st):
     """The stride-phase MFMA form of dX against the gather from the canonical kernel, including a layer
-    whose stride exceeds its kernel (pixels no patch covers get a zero gradient)."""
+    whose stride exceeds its kernel (pixels no patch covers get a zero gradient).  With four input channels both
+    calls run the one-thread-per-pixel kernel: once with ELU' folded into its reads, once on a gradient masked
+    beforehand (that kernel against the float64 restatement: test_encoder_forward_and_backward)."""
     import rl_gan_amd as R
     from gpu_util import close
     rng = np.random.RandomState(h + k)

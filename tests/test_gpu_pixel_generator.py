@@ -64,9 +64,15 @@ def test_generator_step_matches_restatement(n, a_dim):
         want = opt.step(w0, L.grad.cpu().numpy())
         np.testing.assert_allclose(L.canon.cpu().numpy(), want, rtol=0, atol=2e-7)
     for L in gen.decoder.layers:
-        wm = L.wmat.cpu().numpy()[:L.c_in * L.kk].reshape(L.c_in, L.kk)
         kern, _ = L.kernel_bias()
-        np.testing.assert_array_equal(wm, kern.reshape(L.kk, L.c_in).T)
+        if L.fused:                                         # the two fragment images of the fused kernels
+            nk = L.kk * L.c_in
+            for m, img in ((L.map_f, L.wfrag), (L.map_dx, L.wdx)):
+                np.testing.assert_array_equal(img.cpu().numpy()[m.cpu().numpy()[:nk]], kern.ravel())
+        else:
+            wm = L.wmat.cpu().numpy()[:L.c_in * L.kk].reshape(L.c_in, L.kk)
+            np.testing.assert_array_equal(wm, kern.reshape(L.kk, L.c_in).T)
+    assert [L.fused for L in gen.decoder.layers] == [False, False, True, True]
     # the encoder is not in the generator's var_list
     for t, L in zip(enc_before, enc.layers + [enc.head]):
         assert torch.equal(t, L.canon)

@@ -94,13 +94,15 @@ def pixel_curious_gan(B=4096, a_dim=6):
 WORKLOADS = (("conv_ddpg_doom_84_b4096", conv_ddpg_doom), ("pixel_curious_gan_universe_42_b4096", pixel_curious_gan))
 
 
-def run_all(B=4096, seconds=1.5):
+def run_all(B=4096, seconds=1.5, only=None):
     """[{workload, value (updates/s at batch B), ms_per_step, transitions_per_s, steps}] -- a failed workload is
     reported with its error instead of a value, never silently dropped."""
     import gc
     import torch
     out = []
     for name, build in WORKLOADS:
+        if only and name != only:
+            continue
         try:
             step = build(B)
             ms, n = time_steps(step, seconds)
@@ -115,4 +117,4 @@ def run_all(B=4096, seconds=1.5):
 
 
 if __name__ == "__main__":
-    print(json.dumps(run_all(int(sys.argv[1]) if len(sys.argv) > 1 else 4096), indent=1))
+    print(json.dumps(run_all(int(sys.argv[1]) if len(sys.argv) > 1 else 4096, only=sys.argv[2] if len(sys.argv) > 2 else None), indent=1))
