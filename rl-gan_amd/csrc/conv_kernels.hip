@@ -694,7 +694,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_small_kernel(const ConvG g, co
 // grad[(k, n)] in canonical order ([K][Cout] kernel, then bias[Cout]) = sum of the slabs.  A workgroup
 // handles 16 entries; 16 threads per entry each add a strided share of the slabs in index order and the
 // 16 partial sums are added in a fixed order, so the result does not depend on timing.
-__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __restrict__ slabs, int n_slabs, int KP, int NP,
+// `every`: the slabs to add are every `every`-th one (1: all of them; FOLD: the group sums conv_wgrad_fold_kernel left).
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __restrict__ slabs, int n_slabs, int every, int KP, int NP,
                                                                 int K, int Cout, float* __restrict__ grad) {
   // 64 consecutive gradient entries per workgroup (neighbouring lanes read neighbouring floats of a slab), four
   // slab phases per entry, each with four loads in flight; the phases meet in LDS and are added in phase order
@@ -706,7 +707,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __r
   if (i < total) {
     const int k = i / Cout, n = i - k * Cout;
     const float* p = slabs + (size_t)k * NP + n;
-    const size_t st = (size_t)KP * NP;
+    const size_t st = (size_t)KP * NP * every;
     int q = ph;
     for (; q + 12 < n_slabs; q += 16) {
       const float a = p[(size_t)q * st], b = p[(size_t)(q + 4) * st], c = p[(size_t)(q + 8) * st], d = p[(size_t)(q + 12) * st];
@@ -717,6 +718,43 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __r
   part[ph][col] = s;
   __syncthreads();
   if (ph == 0 && i < total) grad[i] = ((part[0][col] + part[1][col]) + part[2][col]) + part[3][col];
+}
+
+// With thousands of slabs the kernel above is a few workgroups walking long chains of loads.  This one goes first
+// then: slabs in groups of FOLD, one workgroup per (64 entries, group), the group's sum left in the group's first slab
+// (every entry of that slab is read by the one workgroup that later overwrites it, behind its barrier).  Groups in
+// order, four phases per group in order: still one fixed order of additions.
+constexpr int FOLD = 32;
+__global__ __launch_bounds__(256) void conv_wgrad_fold_kernel(float* __restrict__ slabs, int n_slabs, int slab_floats) {
+  __shared__ float part[4][64];
+  const int col = threadIdx.x & 63, ph = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + col;
+  const int q0 = blockIdx.y * FOLD, q1 = min(n_slabs, q0 + FOLD);
+  float s = 0.f;
+  if (i < slab_floats) {
+    const float* p = slabs + i;
+    float v[FOLD / 4];
+#pragma unroll
+    for (int j = 0; j < FOLD / 4; ++j) { const int q = q0 + ph + 4 * j; v[j] = q < q1 ? p[(size_t)q * slab_floats] : 0.f; }
+#pragma unroll
+    for (int j = 0; j < FOLD / 4; ++j) s += v[j];
+  }
+  part[ph][col] = s;
+  __syncthreads();
+  if (ph == 0 && i < slab_floats) slabs[(size_t)q0 * slab_floats + i] = ((part[0][col] + part[1][col]) + part[2][col]) + part[3][col];
+}
+
+// all slabs into grad, through the folding step when there are many
+inline int reduce_slabs(float* slabs, int used, int KP, int NP, int K, int Cout, float* grad, hipStream_t st) {
+  int every = 1;
+  if (used > 2 * FOLD) {
+    hipLaunchKernelGGL(conv_wgrad_fold_kernel, dim3(cdiv(KP * NP, 64), cdiv(used, FOLD)), dim3(256), 0, st, slabs, used, KP * NP);
+    if (const int rc = (int)hipGetLastError()) return rc;
+    every = FOLD;
+    used = cdiv(used, FOLD);
+  }
+  hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(cdiv((K + 1) * Cout, 64)), dim3(256), 0, st, slabs, used, every, KP, NP, K, Cout, grad);
+  return (int)hipGetLastError();
 }
 
 // fragment images of the input-gradient classes: offsets and total size (0 when the layer is outside
@@ -786,8 +824,7 @@ int launch_wgrad(const ConvG& g, const S& src, const float* dz, const float* y_e
       hipLaunchKernelGGL((conv_wgrad_small_kernel<2, 8, S>), grid, block, lds, st, g, src, dz, y_elu, slabs, M, per);
     }
     if (const int rc = launched()) return rc;
-    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(cdiv((g.K + 1) * g.Cout, 64)), dim3(256), 0, st, slabs, used, KP, NP, g.K, g.Cout, grad);
-    return launched();
+    return reduce_slabs(slabs, used, KP, NP, g.K, g.Cout, grad, st);
   }
   const int per = cdiv(cdiv(M, n_slabs), WG_PIX) * WG_PIX;  // pixels per workgroup, a multiple of the staging step
   const int used = cdiv(M, per);                            // slabs actually written (<= n_slabs)
@@ -808,8 +845,7 @@ int launch_wgrad(const ConvG& g, const S& src, const float* dz, const float* y_e
   }
 #undef RLGAN_WG
   if (const int rc = launched()) return rc;
-  hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(cdiv((g.K + 1) * g.Cout, 64)), dim3(256), 0, st, slabs, used, KP, NP, g.K, g.Cout, grad);
-  return launched();
+  return reduce_slabs(slabs, used, KP, NP, g.K, g.Cout, grad, st);
 }
 
 // uint8 source of a first layer: argument checks shared by the two entry points

@@ -54,8 +54,12 @@ def conv_ddpg_doom(B=4096, a_dim=6):
     r = torch.rand((B, 1), generator=g, device="cuda", dtype=torch.float32)
 
     def step():
-        critic.learn(s, a, r, s_n)
-        actor.learn(s, critic)
+        # neither step trains the encoder (Conv_model.py:616,784), so the features of s serve both: two encoder passes per
+        # update where the reference's two sess.run calls make three
+        phis_n = enc.forward(s_n).clone()
+        phis = enc.forward(s)
+        critic.learn(None, a, r, None, phis=phis, phis_next=phis_n)
+        actor.learn(None, critic, phis=phis)
     return step
 
 
