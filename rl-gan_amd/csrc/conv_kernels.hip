@@ -473,6 +473,125 @@ __global__ __launch_bounds__(256) void conv_dx_kernel(const ConvG g, const DxOff
   }
 }
 
+// The same product for a layer whose dZ image fits LDS and whose per-class kernel fragments fit a wave's registers
+// (the 3x3 stride-2 layers of the encoders): a workgroup owns ONE image, multiplies dZ by ELU' once while staging it,
+// and walks the classes one after the other; inside a class a wave keeps the class's kernel fragments in registers
+// and walks its share of the 16-pixel tiles, gathering dZ rows from LDS.  conv_dx_kernel above fetches every dZ row
+// (and the layer output beside it) from memory once per tap and every kernel fragment once per 16 pixels.
+constexpr int DXI_MAXF = 16;               // kernel fragments (k-groups x input-channel tiles) of a class held by a wave
+
+// One class of one image for one wave.  NGC = the class's k-groups when it is one of the counts instantiated below
+// (loops unrolled: the gathers of a tile are all requested before its first MFMA), 0 = any count up to DXI_MAXF / NT.
+template <int NT, int NGC>
+__device__ __forceinline__ void dx_img_class(const ConvG& g, const DxClass& c, FastDiv dnb, const float* __restrict__ Z, int ZS,
+                                             const int* __restrict__ tapd, const int* __restrict__ tapuv,
+                                             const float* __restrict__ wl, float* __restrict__ dx0, int imgs) {
+  constexpr int MAXG = NGC > 0 ? NGC : DXI_MAXF / NT;
+  const int lane = threadIdx.x & 63, wave = wave_id(), q0 = lane >> 4;
+  const int ng = NGC > 0 ? NGC : c.NG;
+  const int per = c.na * c.nb, ntiles = cdiv(per, 16);
+  f32x4 w[MAXG * NT];
+  int td[MAXG], tu[MAXG], tv[MAXG];
+#pragma unroll
+  for (int gi = 0; gi < MAXG; ++gi) {
+    const bool in = gi < ng;
+#pragma unroll
+    for (int i = 0; i < NT; ++i) w[gi * NT + i] = in ? *(const f32x4*)(wl + (gi * NT + i) * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const int tuv = in ? tapuv[4 * gi + q0] : -1;
+    td[gi] = in ? tapd[4 * gi + q0] : 0;
+    tu[gi] = tuv < 0 ? 0x10000 : (tuv & 0xffff);          // a tap outside the class's list: a row no pixel has
+    tv[gi] = tuv < 0 ? 0 : (tuv >> 16);
+  }
+  // the (image, tile) pairs of the workgroup's images go round the waves
+  int img = 0, t = wave;
+  while (t >= ntiles && img < imgs) { t -= ntiles; ++img; }
+  for (; img < imgs;) {
+    const int p = min(16 * t + (lane & 15), per - 1);
+    const int a = fdiv(p, dnb), bb = p - a * c.nb;
+    const int pz = (img * g.Ho * g.Wo + a * g.Wo + bb) * ZS;
+    float* dxn = dx0 + (size_t)img * g.H * g.W * g.Cin;
+    f32x4 ad[MAXG];
+#pragma unroll
+    for (int gi = 0; gi < MAXG; ++gi) {
+      const bool ok = (unsigned)(a - tu[gi]) < (unsigned)g.Ho && (unsigned)(bb - tv[gi]) < (unsigned)g.Wo;
+      ad[gi] = *(const f32x4*)(Z + (ok ? pz + td[gi] : 0));
+      if (!ok) ad[gi] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    f32x4 acc[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int gi = 0; gi < MAXG; ++gi) {
+      if (NGC > 0 || gi < ng) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+#pragma unroll
+          for (int i = 0; i < NT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[gi * NT + i][m], ad[gi][m], acc[i], 0, 0, 0);
+        }
+      }
+    }
+    if (16 * t + (lane & 15) < per) {
+      float* o = dxn + ((size_t)(g.s * a + c.py) * g.W + (g.s * bb + c.px)) * g.Cin;
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        const int n0 = 16 * i + q0 * 4;
+        if (n0 < g.Cin) *(f32x4*)(o + n0) = acc[i];
+      }
+    }
+    t += 4;
+    while (t >= ntiles && img < imgs) { t -= ntiles; ++img; }
+  }
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void conv_dx_img_kernel(const ConvG g, const DxOff offs, const float* __restrict__ dz,
+                                                          const float* __restrict__ yelu, const float* __restrict__ wdx,
+                                                          float* __restrict__ dx, int n_images, int imgs_per_wg) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int ZS = g.Cout + 4, C4 = g.Cout >> 2;
+  const int n = blockIdx.x * imgs_per_wg, imgs = min(imgs_per_wg, n_images - n);
+  const int npix = imgs * g.Ho * g.Wo;                   // the images of this workgroup, one after the other
+  float* Z = lds;                                        // [imgs][Ho * Wo][Cout + 4]
+  int* tab = (int*)(lds + imgs_per_wg * g.Ho * g.Wo * ZS);   // per class: [max_ng * 4] offsets, then [max_ng * 4] taps
+  const int ncls = g.s * g.s, tl = offs.max_ng * 4;
+  const f32x4* dz4 = (const f32x4*)(dz + (size_t)n * g.Ho * g.Wo * g.Cout);
+  const f32x4* y4 = (const f32x4*)(yelu + (size_t)n * g.Ho * g.Wo * g.Cout);
+  for (int i = threadIdx.x; i < npix * C4; i += 256) {
+    f32x4 z = dz4[i];
+    if (yelu) {
+      const f32x4 y = y4[i];
+      z = f32x4{z[0] * elu_d(y[0]), z[1] * elu_d(y[1]), z[2] * elu_d(y[2]), z[3] * elu_d(y[3])};
+    }
+    const int p = i / C4;
+    *(f32x4*)(Z + p * ZS + 4 * (i - p * C4)) = z;
+  }
+  for (int i = threadIdx.x; i < ncls * tl; i += 256) {
+    const int cls = i / tl, q = i - cls * tl;
+    const DxClass c = dx_class(g, cls);
+    const int kk0 = q * 4, tap = c.nkx > 0 ? kk0 / g.Cout : 0, co = kk0 - tap * g.Cout;
+    const int u = c.nkx > 0 ? tap / c.nkx : 0, v = tap - u * c.nkx;
+    const bool in = kk0 < c.Kc;
+    tab[2 * cls * tl + q] = in ? (-u * g.Wo - v) * ZS + co : 0;
+    tab[(2 * cls + 1) * tl + q] = in ? (u | (v << 16)) : -1;
+  }
+  __syncthreads();
+  float* dxn = dx + (size_t)n * g.H * g.W * g.Cin;
+  const int imgs_here = imgs;
+  for (int cls = 0; cls < ncls; ++cls) {                   // no barrier below: every wave walks the classes at its own pace
+    const DxClass c = dx_class(g, cls);
+    const int *tapd = tab + 2 * cls * tl, *tapuv = tapd + tl;
+    const float* wl = wdx + offs.off[cls] + (threadIdx.x & 63) * 4;
+    switch (c.NG) {
+      case 0: break;
+      case 1: dx_img_class<NT, 1>(g, c, offs.dnb[cls], Z, ZS, tapd, tapuv, wl, dxn, imgs_here); break;
+      case 2: dx_img_class<NT, 2>(g, c, offs.dnb[cls], Z, ZS, tapd, tapuv, wl, dxn, imgs_here); break;
+      case 4: dx_img_class<NT, 4>(g, c, offs.dnb[cls], Z, ZS, tapd, tapuv, wl, dxn, imgs_here); break;
+      case 8: dx_img_class<NT, 8>(g, c, offs.dnb[cls], Z, ZS, tapd, tapuv, wl, dxn, imgs_here); break;
+      default: dx_img_class<NT, 0>(g, c, offs.dnb[cls], Z, ZS, tapd, tapuv, wl, dxn, imgs_here); break;
+    }
+  }
+}
+
 // ---------------------------------------------------------------- weight gradient
 // dW[K+1, Cout] = [P 1]^T dZ reduced over all output pixels.  A workgroup walks its share of the
 // pixels WG_PIX at a time: patches and dZ rows are staged in LDS, wave w owns the 16-row strips
@@ -957,6 +1076,24 @@ int rlgan_conv_backward_input(const rlgan_conv_t* conv, const float* dz, const f
   if (wdx) {
     DxOff offs;
     if (dx_layout(g, &offs) == 0) return RLGAN_E_DIMS;
+    const int ntc = cdiv(g.Cin, 16);
+    const size_t zimg = (size_t)g.Ho * g.Wo * (g.Cout + 4) * sizeof(float), tabs = (size_t)2 * g.s * g.s * std::max(1, offs.max_ng) * 4 * sizeof(int);
+    // images per workgroup: a class's kernel fragments are fetched once per workgroup, so several small images share them
+    const int ipw = (int)std::max<size_t>(1, std::min<size_t>(8, (48 * 1024 - tabs) / zimg));
+    const size_t ilds = ipw * zimg + tabs;
+    if (ntc <= 2 && offs.max_ng * ntc <= DXI_MAXF && ilds <= 64 * 1024 && !(((uintptr_t)dx | (uintptr_t)dz | (uintptr_t)y_elu) & 15)) {
+      // pixels no class covers (stride beyond the kernel) keep the zeros of the other kernel's classes: every class
+      // with taps writes all of its pixels, a class without taps (NG == 0) must still be cleared
+      bool all_have_taps = true;
+      for (int cls = 0; cls < g.s * g.s; ++cls) all_have_taps = all_have_taps && dx_class(g, cls).NG > 0;
+      if (all_have_taps) {
+        hipStream_t st = (hipStream_t)stream;
+        const dim3 gi(cdiv(n_images, ipw));
+        if (ntc == 1) hipLaunchKernelGGL(conv_dx_img_kernel<1>, gi, dim3(256), ilds, st, g, offs, dz, y_elu, wdx, dx, n_images, ipw);
+        else hipLaunchKernelGGL(conv_dx_img_kernel<2>, gi, dim3(256), ilds, st, g, offs, dz, y_elu, wdx, dx, n_images, ipw);
+        return launched();
+      }
+    }
     const long long per = (long long)cdiv(g.H, g.s) * cdiv(g.W, g.s);          // pixels per image of the largest class
     if ((long long)n_images * per > 0x7fffffffll || ((uintptr_t)dx & 15)) return RLGAN_E_ALIGN;
     const long long groups = cdiv((long long)n_images * per, 64);
