@@ -8,7 +8,8 @@ import rl_gan_amd as R
 from kbench import timeit
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-for name, hw, spec in (("doom 84x84x4", 84, R.DOOM_HEAD), ("universe(2) 84x84x4", 84, R.universe_head(2)), ("universe(4) 42x42x4", 42, R.universe_head(4))):
+for name, hw, spec in (("doom 84x84x4", 84, R.DOOM_HEAD), ("universe(2) 84x84x4", 84, R.universe_head(2)), ("universe(4) 42x42x4", 42, R.universe_head(4)),
+                       ("universe(2) 42x42x4", 42, R.universe_head(2))):
     enc = R.ConvEncoder(hw, hw, 4, spec, rng=np.random.RandomState(0), bias_init=0.001)
     x = torch.rand(B, hw, hw, 4, device="cuda")
     feat = enc.forward(x)
