@@ -810,6 +810,129 @@ __global__ __launch_bounds__(256) void conv_wgrad_small_kernel(const ConvG g, co
   }
 }
 
+// Weight gradient of a first layer (four input channels, at most 47 patch elements: the 3x3 kernels of the
+// "universe" encoders) with whole images in LDS.  The kernels above copy every input pixel into each of the patches
+// it belongs to before multiplying; here a workgroup stages the image once as it lies in memory ([H*W][4]) and dZ of
+// the image transposed ([pixel/4][channel][4 pixels], times ELU'), and the row operand of the product
+//   dW[(tap, ci) | bias][co] += sum over output pixels of X[pixel(tap)][ci] * dZ[pixel][co]
+// is gathered from the image in LDS: lane (i, q) reads X at pixel offset (table in LDS, four pixels per read) + its own
+// tap offset; the bias row multiplies by one.  The 16-pixel groups of an image go round the four waves; a workgroup
+// walks a chunk of images and leaves one slab, the four waves' sums added in wave order.
+constexpr int C4W_RT = 3;                  // row tiles: (k*k*4 + 1) <= 48
+template <int NT, int XU, int ZU, class S>
+__global__ __launch_bounds__(256) void conv_wgrad_c4_kernel(const ConvG g, const S src, const float* __restrict__ dz,
+                                                            const float* __restrict__ yelu, float* __restrict__ slabs,
+                                                            int n_images, int per_wg) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int HW = g.H * g.W, npix = g.Ho * g.Wo, NG16 = cdiv(npix, 16), PP = NG16 * 16;
+  float* X = lds;                                        // [H * W][4]
+  float* Zt = lds + HW * 4;                              // [PP / 4][Cout][4], zeros beyond the image's pixels
+  unsigned short* pixtab = (unsigned short*)(Zt + PP * g.Cout);   // [PP] offset of the patch's first element in X (16 bits: two workgroups must fit a compute unit's LDS)
+  const int lane = threadIdx.x & 63, wave = wave_id(), q = lane >> 4, j = lane & 15;
+  for (int p = threadIdx.x; p < PP; p += 256) {
+    const int pc = min(p, npix - 1), oy = fdiv(pc, g.dWo), ox = pc - oy * g.Wo;
+    pixtab[p] = (unsigned short)(((g.s * oy) * g.W + g.s * ox) * 4);
+  }
+  for (int i = threadIdx.x; i < (PP - npix) * g.Cout; i += 256) {   // pixels past the image's last: zero, never overwritten
+    const int p = npix + i / g.Cout, co = i % g.Cout;
+    Zt[((p >> 2) * g.Cout + co) * 4 + (p & 3)] = 0.f;
+  }
+  int tapoff[C4W_RT];
+  float one[C4W_RT], live[C4W_RT];
+#pragma unroll
+  for (int rt = 0; rt < C4W_RT; ++rt) {
+    const int e = 16 * rt + j, ec = min(e, g.K - 1), tap = ec >> 2, ky = tap / g.k, kx = tap - ky * g.k;
+    tapoff[rt] = (ky * g.W + kx) * 4 + (ec & 3);
+    one[rt] = e == g.K ? 1.f : 0.f;                      // the bias row
+    live[rt] = e < g.K ? 1.f : 0.f;
+  }
+  f32x4 acc[C4W_RT][NT];
+#pragma unroll
+  for (int rt = 0; rt < C4W_RT; ++rt) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[rt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const int n0 = blockIdx.x * per_wg, n1 = min(n_images, n0 + per_wg);
+  // An image's operands travel memory -> registers while the previous image is multiplied out of LDS: XU input pixels
+  // and ZU four-channel pieces of dY and of the layer output per thread (the host checked that these cover an image).
+  const int C4 = g.Cout >> 2, total = npix * C4;
+  typename S::Raw xr[XU];
+  f32x4 dr[ZU], yr[ZU];
+  long long base_next = -1;
+  auto fetch = [&](int n) {
+    base_next = src.image(n);
+#pragma unroll
+    for (int u = 0; u < XU; ++u) xr[u] = src.load(base_next, (size_t)4 * min((int)threadIdx.x + 256 * u, HW - 1));
+    const f32x4* dz4 = (const f32x4*)(dz + (size_t)n * npix * g.Cout);
+    const f32x4* y4 = (const f32x4*)(yelu + (size_t)n * npix * g.Cout);
+#pragma unroll
+    for (int u = 0; u < ZU; ++u) {
+      const int i = min((int)threadIdx.x + 256 * u, total - 1);
+      dr[u] = dz4[i];
+      yr[u] = yelu ? y4[i] : f32x4{1.f, 1.f, 1.f, 1.f};
+    }
+  };
+  if (n0 < n1) fetch(n0);
+  for (int n = n0; n < n1; ++n) {
+    __syncthreads();                                     // the previous image's operands have been read
+    const long long base = base_next;
+#pragma unroll
+    for (int u = 0; u < XU; ++u) {
+      const int i = threadIdx.x + 256 * u;
+      if (i < HW) *(f32x4*)(X + 4 * i) = src.value(xr[u], base);
+    }
+#pragma unroll
+    for (int u = 0; u < ZU; ++u) {
+      const int i = threadIdx.x + 256 * u;
+      if (i < total) {
+        const int p = i / C4, c0 = 4 * (i - p * C4);
+        float* zt = Zt + ((p >> 2) * g.Cout + c0) * 4 + (p & 3);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) zt[4 * c] = dr[u][c] * elu_d(yr[u][c]);
+      }
+    }
+    __syncthreads();
+    if (n + 1 < n1) fetch(n + 1);
+    for (int G = wave; G < NG16; G += 4) {
+      const uint2 pk = *(const uint2*)(pixtab + 16 * G + 4 * q);
+      const int pt[4] = {(int)(pk.x & 0xffffu), (int)(pk.x >> 16), (int)(pk.y & 0xffffu), (int)(pk.y >> 16)};
+      f32x4 bz[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) bz[nt] = *(const f32x4*)(Zt + ((4 * G + q) * g.Cout + 16 * nt + j) * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+#pragma unroll
+        for (int rt = 0; rt < C4W_RT; ++rt) {
+          if (rt < g.NG) {
+            const float av = X[pt[e] + tapoff[rt]] * live[rt] + one[rt];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[rt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bz[nt][e], acc[rt][nt], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  float* red = X;                                        // [4 waves][C4W_RT * NT tiles][64 lanes][4]
+  constexpr int TILES = C4W_RT * NT;
+#pragma unroll
+  for (int rt = 0; rt < C4W_RT; ++rt) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) *(f32x4*)(red + ((wave * TILES + rt * NT + nt) * 64 + lane) * 4) = acc[rt][nt];
+  }
+  __syncthreads();
+  const int NP = NT * 16;
+  float* out = slabs + (size_t)blockIdx.x * (g.NG * 16) * NP;
+  for (int i = threadIdx.x; i < TILES * 256; i += 256) {
+    const int tile = i >> 8, el = i & 255, ln = el >> 2, r = el & 3;
+    const int rt = tile / NT, nt = tile - rt * NT;
+    if (rt < g.NG) {
+      const float* pr = red + tile * 256 + el;
+      out[(16 * rt + 4 * (ln >> 4) + r) * NP + 16 * nt + (ln & 15)] = ((pr[0] + pr[TILES * 256]) + pr[2 * TILES * 256]) + pr[3 * TILES * 256];
+    }
+  }
+}
+
 // grad[(k, n)] in canonical order ([K][Cout] kernel, then bias[Cout]) = sum of the slabs.  A workgroup
 // handles 16 entries; 16 threads per entry each add a strided share of the slabs in index order and the
 // 16 partial sums are added in a fixed order, so the result does not depend on timing.
@@ -930,6 +1053,26 @@ int launch_wgrad(const ConvG& g, const S& src, const float* dz, const float* y_e
   const long long Ml = (long long)n_images * g.Ho * g.Wo;
   if (Ml > 0x7fffffffll || ((uintptr_t)dz & 15) || (y_elu && ((uintptr_t)y_elu & 15))) return RLGAN_E_ALIGN;
   const int M = (int)Ml;
+  if (g.Cin == 4 && g.NG <= C4W_RT && g.NT <= 2) {            // a first layer with whole images in LDS
+    constexpr int XU = 7, ZU = 13;                            // per-thread pieces of an image in flight: 42x42 frames, 20x20x32 maps
+    const int HW = g.H * g.W, PP = cdiv(g.Ho * g.Wo, 16) * 16;
+    const size_t lds = ((size_t)HW * 4 + (size_t)PP * g.Cout) * sizeof(float) + (size_t)PP * sizeof(unsigned short);
+    if (lds <= 79 * 1024 && (size_t)HW * 16 < 65536 && (size_t)4 * C4W_RT * g.NT * 256 <= (size_t)HW * 4 &&   // two workgroups per compute unit; 16-bit offsets; the wave sums fit the image's space
+        HW <= 256 * XU && g.Ho * g.Wo * (g.Cout / 4) <= 256 * ZU) {
+      const int wgs = std::min(n_slabs, std::min(n_images, 512));
+      const int per = cdiv(n_images, wgs), used = cdiv(n_images, per);
+      hipStream_t st = (hipStream_t)stream;
+      if (g.NT == 1) {
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)conv_wgrad_c4_kernel<1, XU, ZU, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((conv_wgrad_c4_kernel<1, XU, ZU, S>), dim3(used), dim3(256), lds, st, g, src, dz, y_elu, slabs, n_images, per);
+      } else {
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)conv_wgrad_c4_kernel<2, XU, ZU, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((conv_wgrad_c4_kernel<2, XU, ZU, S>), dim3(used), dim3(256), lds, st, g, src, dz, y_elu, slabs, n_images, per);
+      }
+      if (const int rc = launched()) return rc;
+      return reduce_slabs(slabs, used, g.NG * 16, g.NT * 16, g.K, g.Cout, grad, st);
+    }
+  }
   if (g.NG <= 8 && g.NT <= 2 && M / n_slabs >= 256) {        // few patch elements and long pixel ranges: one slab per wave, no workgroup barriers
     const int KP = g.NG * 16, NP = g.NT * 16;
     const int per = cdiv(cdiv(M, n_slabs), 16) * 16, used = cdiv(M, per);
