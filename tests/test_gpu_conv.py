@@ -132,7 +132,8 @@ def test_input_gradient_two_ways(h, cin, cout, k, st):
     close(a.cpu().numpy(), b.cpu().numpy().astype(np.float64), what="dX mfma vs gather")
 
 
-@pytest.mark.parametrize("h,cin,cout,k,st,n", [(84, 4, 8, 5, 4, 7), (42, 4, 32, 3, 2, 9), (20, 8, 16, 3, 2, 40)])
+@pytest.mark.parametrize("h,cin,cout,k,st,n", [(84, 4, 8, 5, 4, 7), (42, 4, 32, 3, 2, 9), (20, 8, 16, 3, 2, 40), (42, 4, 32, 3, 2, 30),
+                                               (21, 4, 16, 3, 2, 11)])
 def test_weight_gradient_two_ways(h, cin, cout, k, st, n):
     """Layers with few patch elements have two weight-gradient kernels (one slab per workgroup, or per wave when
     every slab covers a long run of pixels): both against the float64 restatement, on float32 frames and on the
@@ -153,7 +154,10 @@ def test_weight_gradient_two_ways(h, cin, cout, k, st, n):
     want = np.concatenate([dw.ravel(), db.ravel()])
     m = n * L.h_out * L.w_out
     got = {}
-    for ns in (1024, max(4, m // 300)):          # pixels per slab: few (workgroup kernel) / at least 256 (wave kernel)
+    # pixels per slab: few (workgroup kernel) / at least 256 (wave kernel); a 3x3 first layer on small frames runs the
+    # image-in-LDS kernel either way, one image per workgroup, and with 4 slabs several images per workgroup (the next
+    # image is fetched while the current one is multiplied)
+    for ns in (1024, max(4, m // 300)) + ((4,) if cin == 4 and k == 3 else ()):
         L.n_slabs, L._small = ns, False
         L.grad.zero_()
         L.backward(x, y, dy, need_dx=False)
