@@ -464,8 +464,10 @@ int rlgan_gather_map(const float* src, const int32_t* map, int32_t n, float* dst
 
 /* ---- the same layers without the cols matrix in memory (dec_deconv3 and dec_deconv4, Conv_model.py:468-473) ----
  * Two stride-2 shapes run as fused kernels: 8x8x64 -> 19x19x32 with a 5x5 kernel (kind 1) and 19x19x32 -> 42x42x1
- * with a 6x6 kernel (kind 2); rlgan_deconv_fused_geometry reports kind 0 for every other shape, which keeps the
- * cols form above.  The kernel is read from two fragment images filled from the canonical vector through
+ * with a 6x6 kernel (kind 2); 3x3x128 -> 8x8x64 with a 4x4 kernel (dec_deconv2, Conv_model.py:463) has a fused FORWARD
+ * pass only (kind 3: wff alone, map_fb may be NULL, no workspace, rlgan_deconv_fused_backward refuses it with
+ * RLGAN_E_DIMS; its backward pass is the cols form, so the layer keeps Wmat as well);
+ * rlgan_deconv_fused_geometry reports kind 0 for every other shape, which keeps the cols form above.  The kernel is read from two fragment images filled from the canonical vector through
  * rlgan_deconv_fused_build_maps + rlgan_pack_weights (or by rlgan_apply, map_f/wf and map_b/wb): wff for the
  * forward pass, wfb for the input gradient; both must start as zeros (their padding is never written).
  * Results: the values of the cols form up to the order of the float32 additions inside a product; taps are added

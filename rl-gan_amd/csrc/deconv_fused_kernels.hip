@@ -9,6 +9,9 @@
 //                 output channel are the MFMA columns; the per-image cols matrix (361 x 36) lives in LDS and the
 //                 placement gathers from there.
 //
+//   few-pixel     3x3x128 -> 8x8x64, 4x4 kernel (dec_deconv2, Conv_model.py:463), forward only: sixteen images are the
+//   layer         rows of a tile, see deconv_few_fwd_kernel; its backward pass keeps the cols form.
+//
 // Backward passes read the output gradient from LDS through the same pixel arithmetic: dX = sum over taps of
 // dZ[pixel(tap)] * W_tap^T, dW_tap = sum over images and pixels of dZ[pixel(tap)]^T * X, with per-chunk partial
 // kernels added in chunk order (the same bits every run).  Other shapes keep the cols form of deconv_kernels.hip.
@@ -264,6 +267,87 @@ __global__ __launch_bounds__(256) void deconv_tile_dw_kernel(const float* __rest
 }
 
 // ------------------------------------------------------------------------------------------------
+// few-pixel layer, forward only: 3x3x128 -> 8x8x64, 4x4 kernel (dec_deconv2, Conv_model.py:463)
+// ------------------------------------------------------------------------------------------------
+// With nine input pixels per image the rows of a matrix tile are IMAGES: output pixel (oy, ox) of sixteen images is
+// one product of the channels of the 1, 2 or 4 input pixels that reach it with the taps they reach it through.  The
+// output pixels of one stride phase (oy % 2, ox % 2) form a 4x4 grid fed by the phase's four taps, tap (u, v) of the
+// phase carrying input pixel (iy, ix) to grid point (iy + u, ix + v): a wave owns a 16-channel output tile, holds
+// the phase's sixteen accumulator tiles and, tap by tap, the tap's kernel fragments (fetched once per tap and used
+// for all nine pixels); the sixteen images' inputs sit in LDS.  Taps in ascending (ky, kx) order per output pixel.
+template <int H_, int CI_, int CO_, int K_>
+struct FewT {
+  static constexpr int H = H_, CI = CI_, CO = CO_, K = K_;
+  static constexpr int P = H * H, KG = CI / 16, CT = CO / 16, HO = (H - 1) * 2 + K, NPIX = HO * HO, TAPS = K * K, KW = TAPS * CO * CI;
+  static constexpr int GA = H + K / 2 - 1;                 // grid points of a phase per dimension
+  static_assert(K % 2 == 0 && CT == 4 && CI % 16 == 0 && HO == 2 * GA, "few-pixel layer shape");
+  static constexpr int XS = P * CI + 4;                    // image stride in LDS: sixteen rows on sixteen different bank groups
+  static constexpr int FWD_LDS = 16 * XS * 4;
+};
+using Few = FewT<3, 128, 64, 4>;
+
+template <class T>
+__global__ __launch_bounds__(256) void deconv_few_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wff,
+                                                              const float* __restrict__ bias, float* __restrict__ y,
+                                                              int n_images, int act) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lane = threadIdx.x & 63, c = wave_id(), q = lane >> 4, j = lane & 15;
+  const int n0 = blockIdx.x * 16;
+  constexpr int ROW4 = T::P * T::CI / 4;                   // float4 per image
+  for (int i = threadIdx.x; i < 16 * ROW4; i += 256) {
+    const int r = i / ROW4, e = i - r * ROW4;
+    const int img = min(n0 + r, n_images - 1);             // rows past the last image repeat it; they are not stored
+    *(f32x4*)(lds + r * T::XS + 4 * e) = *(const f32x4*)(x + ((size_t)img * ROW4 + e) * 4);
+  }
+  __syncthreads();
+  FragSrc ws;
+  ws.set(wff, c * T::KG);
+  const float bj = bias[16 * c + j];
+  const float* xa = lds + j * T::XS + 4 * q;
+  for (int ph = 0; ph < 4; ++ph) {
+    const int ry = ph >> 1, rx = ph & 1;
+    f32x4 acc[T::GA * T::GA];
+#pragma unroll
+    for (int i = 0; i < T::GA * T::GA; ++i) acc[i] = f32x4{bj, bj, bj, bj};
+    f32x4 b[2][T::KG];
+#pragma unroll
+    for (int g = 0; g < T::KG; ++g) b[0][g] = ws.load(((ry * T::K + rx) * T::CT) * T::KG + g);
+#pragma unroll
+    for (int uv = 0; uv < (T::K / 2) * (T::K / 2); ++uv) {
+      const int u = uv / (T::K / 2), v = uv % (T::K / 2);
+      if (uv + 1 < (T::K / 2) * (T::K / 2)) {
+        const int un = (uv + 1) / (T::K / 2), vn = (uv + 1) % (T::K / 2);
+        const int tapn = (ry + 2 * un) * T::K + rx + 2 * vn;
+#pragma unroll
+        for (int g = 0; g < T::KG; ++g) b[(uv + 1) & 1][g] = ws.load((tapn * T::CT) * T::KG + g);
+      }
+#pragma unroll
+      for (int p = 0; p < T::P; ++p) {
+        const int pos = (p / T::H + u) * T::GA + p % T::H + v;
+#pragma unroll
+        for (int g = 0; g < T::KG; ++g) {
+          const f32x4 a = *(const f32x4*)(xa + p * T::CI + 16 * g);
+#pragma unroll
+          for (int m = 0; m < 4; ++m) acc[pos] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], b[uv & 1][g][m], acc[pos], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < T::GA * T::GA; ++i) {
+      const int oy = 2 * (i / T::GA) + ry, ox = 2 * (i % T::GA) + rx;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int img = n0 + 4 * q + r;
+        if (img < n_images) {
+          const float v = acc[i][r];
+          y[((size_t)img * T::NPIX + oy * T::HO + ox) * T::CO + 16 * c + j] = act ? fmaxf(v, 0.f) : v;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // narrow layer (one output channel)
 // ------------------------------------------------------------------------------------------------
 template <int H_, int CI_, int K_>
@@ -465,12 +549,13 @@ __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__
   grad[p] = tot;
 }
 
-enum { FUSED_NONE = 0, FUSED_TILE = 1, FUSED_NARROW = 2 };
+enum { FUSED_NONE = 0, FUSED_TILE = 1, FUSED_NARROW = 2, FUSED_FEW_FWD = 3 };
 
 inline int fused_kind(const rlgan_deconv_t* d) {
   if (!d || d->h != d->w || d->stride != 2) return FUSED_NONE;
   if (d->h == Mid::H && d->c_in == Mid::CI && d->c_out == Mid::CO && d->k == Mid::K) return FUSED_TILE;
   if (d->h == Last::H && d->c_in == Last::CI && d->c_out == 1 && d->k == Last::K) return FUSED_NARROW;
+  if (d->h == Few::H && d->c_in == Few::CI && d->c_out == Few::CO && d->k == Few::K) return FUSED_FEW_FWD;
   return FUSED_NONE;
 }
 
@@ -497,6 +582,8 @@ int rlgan_deconv_fused_geometry(const rlgan_deconv_t* d, rlgan_deconv_fused_geom
     out->wff_floats = out->wfb_floats = out->kernel_floats = Mid::KW;
     out->max_chunks = Mid::MAX_CHUNKS;
     out->bias_part_floats_per_image = Mid::CO;
+  } else if (kind == FUSED_FEW_FWD) {
+    out->wff_floats = out->kernel_floats = Few::KW;        // forward only: no wfb, no workspace
   } else if (kind == FUSED_NARROW) {
     out->wff_floats = Last::KG * Last::NTN * 256;
     out->wfb_floats = Last::KS * Last::NTC * 64;
@@ -508,7 +595,7 @@ int rlgan_deconv_fused_geometry(const rlgan_deconv_t* d, rlgan_deconv_fused_geom
 
 int64_t rlgan_deconv_fused_workspace(const rlgan_deconv_t* d, int n_images) {
   const int kind = fused_kind(d);
-  if (kind == FUSED_NONE || n_images <= 0) return 0;
+  if (kind == FUSED_NONE || kind == FUSED_FEW_FWD || n_images <= 0) return 0;
   int per, nch;
   if (kind == FUSED_TILE) {
     chunking(n_images, Mid::MAX_CHUNKS, &per, &nch);
@@ -519,15 +606,18 @@ int64_t rlgan_deconv_fused_workspace(const rlgan_deconv_t* d, int n_images) {
 }
 
 int rlgan_deconv_fused_build_maps(const rlgan_deconv_t* d, int32_t* map_ff, int32_t* map_fb) {
-  if (!d || !map_ff || !map_fb) return RLGAN_E_ARG;
+  if (!d || !map_ff) return RLGAN_E_ARG;
   const int kind = fused_kind(d);
   if (kind == FUSED_NONE) return RLGAN_E_DIMS;
+  if (!map_fb && kind != FUSED_FEW_FWD) return RLGAN_E_ARG;
   const int taps = d->k * d->k, CO = d->c_out, CI = d->c_in;
   int p = 0;
   for (int tap = 0; tap < taps; ++tap)
     for (int co = 0; co < CO; ++co)
       for (int ci = 0; ci < CI; ++ci, ++p) {
-        if (kind == FUSED_TILE) {
+        if (kind == FUSED_FEW_FWD) {
+          map_ff[p] = (((tap * Few::CT + co / 16) * Few::KG + ci / 16) * 64 + 16 * ((ci % 16) / 4) + co % 16) * 4 + ci % 4;
+        } else if (kind == FUSED_TILE) {
           // forward: block (tap, channel tile, k-group of input channels); backward: block (input tile, tap, group of output channels)
           map_ff[p] = (((tap * Mid::CT + co / 16) * Mid::KG + ci / 16) * 64 + 16 * ((ci % 16) / 4) + co % 16) * 4 + ci % 4;
           map_fb[p] = ((((ci / 16) * Mid::TAPS + tap) * Mid::KGO + co / 16) * 64 + 16 * ((co % 16) / 4) + ci % 16) * 4 + co % 4;
@@ -536,7 +626,10 @@ int rlgan_deconv_fused_build_maps(const rlgan_deconv_t* d, int32_t* map_ff, int3
           map_fb[p] = ((tap / 4) * Last::NTC + ci / 16) * 64 + 16 * (tap % 4) + ci % 16;
         }
       }
-  for (int co = 0; co < CO; ++co, ++p) map_ff[p] = map_fb[p] = -1;      // the bias is read from the canonical vector
+  for (int co = 0; co < CO; ++co, ++p) {                                // the bias is read from the canonical vector
+    map_ff[p] = -1;
+    if (map_fb) map_fb[p] = -1;
+  }
   return 0;
 }
 
@@ -550,6 +643,10 @@ int rlgan_deconv_fused_forward(const rlgan_deconv_t* d, const float* x, const fl
     allow_lds(deconv_tile_fwd_kernel<Mid>, Mid::FWD_LDS);
     hipLaunchKernelGGL(deconv_tile_fwd_kernel<Mid>, dim3(cdiv(n_images, Mid::IPW)), dim3(256), Mid::FWD_LDS, (hipStream_t)stream,
                        x, wff, bias, y, n_images, act_relu);
+  } else if (kind == FUSED_FEW_FWD) {
+    allow_lds(deconv_few_fwd_kernel<Few>, Few::FWD_LDS);
+    hipLaunchKernelGGL(deconv_few_fwd_kernel<Few>, dim3(cdiv(n_images, 16)), dim3(256), Few::FWD_LDS, (hipStream_t)stream,
+                       x, wff, bias, y, n_images, act_relu);
   } else {
     allow_lds(deconv_narrow_fwd_kernel<Last>, Last::FWD_LDS);
     hipLaunchKernelGGL(deconv_narrow_fwd_kernel<Last>, dim3(n_images), dim3(256), Last::FWD_LDS, (hipStream_t)stream,
@@ -561,7 +658,7 @@ int rlgan_deconv_fused_forward(const rlgan_deconv_t* d, const float* x, const fl
 int rlgan_deconv_fused_backward(const rlgan_deconv_t* d, const float* x, const float* y_relu, const float* dy, const float* wfb,
                                 float* dx, float* workspace, float* grad, int n_images, void* stream) {
   const int kind = fused_kind(d);
-  if (kind == FUSED_NONE) return RLGAN_E_DIMS;
+  if (kind == FUSED_NONE || kind == FUSED_FEW_FWD) return RLGAN_E_DIMS;
   if (!x || !dy || !wfb || !workspace || !grad || n_images <= 0) return RLGAN_E_ARG;
   if (((uintptr_t)x | (uintptr_t)y_relu | (uintptr_t)dy | (uintptr_t)wfb | (uintptr_t)dx | (uintptr_t)workspace | (uintptr_t)grad) & 15)
     return RLGAN_E_ALIGN;

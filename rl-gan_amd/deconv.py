@@ -47,13 +47,19 @@ class DeconvLayer:
         # the two decoder shapes with fused kernels read the kernel from two fragment images instead of wmat
         fg = _lib.DeconvFusedGeom()
         check(lib.rlgan_deconv_fused_geometry(self.spec, C.byref(fg)), "rlgan_deconv_fused_geometry")
-        self.fused = fg.kind != 0 and fused
+        self.fused = fg.kind != 0 and fused                  # forward pass by a fused kernel
+        self.fused_bwd = self.fused and fg.kind != 3          # kind 3: forward only, the backward pass keeps the cols form
         if self.fused:
             mf, mb = np.empty(self.n_params, np.int32), np.empty(self.n_params, np.int32)
-            check(lib.rlgan_deconv_fused_build_maps(self.spec, mf.ctypes.data, mb.ctypes.data), "rlgan_deconv_fused_build_maps")
-            self.map_f, self.map_dx = torch.from_numpy(mf).to(dev), torch.from_numpy(mb).to(dev)
+            check(lib.rlgan_deconv_fused_build_maps(self.spec, mf.ctypes.data, mb.ctypes.data if self.fused_bwd else None),
+                  "rlgan_deconv_fused_build_maps")
+            self.map_f = torch.from_numpy(mf).to(dev)
             self.wfrag = torch.zeros(fg.wff_floats, dtype=torch.float32, device=dev)
-            self.wdx = torch.zeros(fg.wfb_floats, dtype=torch.float32, device=dev)
+            if self.fused_bwd:
+                self.map_dx = torch.from_numpy(mb).to(dev)
+                self.wdx = torch.zeros(fg.wfb_floats, dtype=torch.float32, device=dev)
+            else:                                             # the optimizer's second image is Wmat, which the backward pass reads
+                self.map_dx, self.wdx = self.map_w, self.wmat
             self._ws: Optional[torch.Tensor] = None
         self.grad = torch.zeros(self.n_params, dtype=torch.float32, device=dev)
         self._gmat = torch.empty(g.wmat_floats, dtype=torch.float32, device=dev)
@@ -116,7 +122,7 @@ class DeconvLayer:
         n = x.shape[0]
         rows = n * self.h * self.w
         yr = y.data_ptr() if act else None
-        if self.fused:
+        if self.fused_bwd:
             need = lib.rlgan_deconv_fused_workspace(self.spec, n)
             if self._ws is None or self._ws.numel() < need:
                 self._ws = torch.empty(need, dtype=torch.float32, device=x.device)

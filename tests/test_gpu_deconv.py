@@ -14,7 +14,9 @@ pytestmark = pytest.mark.gpu
                                                 # the two shapes with fused kernels: odd and larger image counts (two images per
                                                 # workgroup forward, chunks of images backward), with and without ReLU
                                                 (8, 64, 32, 5, 2, True, 1), (8, 64, 32, 5, 2, False, 7), (8, 64, 32, 5, 2, True, 150),
-                                                (19, 32, 1, 6, 2, True, 1), (19, 32, 1, 6, 2, False, 70)])
+                                                (19, 32, 1, 6, 2, True, 1), (19, 32, 1, 6, 2, False, 70),
+                                                # forward fused only, sixteen images per workgroup
+                                                (3, 128, 64, 4, 2, True, 16), (3, 128, 64, 4, 2, False, 45)])
 def test_layer_forward_and_backward(h, ci, co, k, s, act, n):
     import rl_gan_amd as R
     from gpu_util import close

@@ -72,7 +72,7 @@ def test_generator_step_matches_restatement(n, a_dim):
         else:
             wm = L.wmat.cpu().numpy()[:L.c_in * L.kk].reshape(L.c_in, L.kk)
             np.testing.assert_array_equal(wm, kern.reshape(L.kk, L.c_in).T)
-    assert [L.fused for L in gen.decoder.layers] == [False, False, True, True]
+    assert [L.fused for L in gen.decoder.layers] == [False, True, True, True] and [L.fused_bwd for L in gen.decoder.layers] == [False, False, True, True]
     # the encoder is not in the generator's var_list
     for t, L in zip(enc_before, enc.layers + [enc.head]):
         assert torch.equal(t, L.canon)

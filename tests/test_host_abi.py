@@ -157,11 +157,12 @@ def test_batchnorm_chunks_cover_the_rows():
         assert 1 < ch <= 128 and ch == -(-m // rows) and rows * ch >= m > rows * (ch - 1)
 
 
-@pytest.mark.parametrize("shape,kind", [((8, 8, 64, 32, 5, 2), 1), ((19, 19, 32, 1, 6, 2), 2), ((3, 3, 128, 64, 4, 2), 0),
-                                        ((8, 8, 64, 32, 5, 1), 0), ((8, 8, 64, 16, 5, 2), 0)])
+@pytest.mark.parametrize("shape,kind", [((8, 8, 64, 32, 5, 2), 1), ((19, 19, 32, 1, 6, 2), 2), ((3, 3, 128, 64, 4, 2), 3),
+                                        ((1, 1, 200, 128, 3, 2), 0), ((8, 8, 64, 32, 5, 1), 0), ((8, 8, 64, 16, 5, 2), 0)])
 def test_fused_decoder_layer_shapes_and_maps(shape, kind):
     """dec_deconv3 and dec_deconv4 (Conv_model.py:468-473) have fused kernels; their two fragment images take every kernel
-    element exactly once and leave the bias out; any other shape reports kind 0 and needs no workspace."""
+    element exactly once and leave the bias out; dec_deconv2 (Conv_model.py:463) has a fused forward pass only (kind 3: one
+    image, no workspace, no fused backward); any other shape reports kind 0 and needs no workspace."""
     d = _lib.Deconv(*shape)
     g = _lib.DeconvFusedGeom()
     assert _lib.lib.rlgan_deconv_fused_geometry(d, C.byref(g)) == 0 and g.kind == kind
@@ -174,6 +175,13 @@ def test_fused_decoder_layer_shapes_and_maps(shape, kind):
         assert _lib.lib.rlgan_deconv_fused_forward(d, 256, 256, 256, 256, 4, 1, None) == -2
         return
     assert g.kernel_floats == n
+    if kind == 3:
+        _lib.check(_lib.lib.rlgan_deconv_fused_build_maps(d, mf.ctypes.data, None))
+        assert np.all(mf[n:] == -1) and mf[:n].min() >= 0 and mf[:n].max() < g.wff_floats and np.unique(mf[:n]).size == n
+        assert g.wfb_floats == 0 and _lib.lib.rlgan_deconv_fused_workspace(d, 64) == 0
+        assert _lib.lib.rlgan_deconv_fused_backward(d, 256, None, 256, 256, None, 256, 256, 4, None) == -2
+        return
+    assert _lib.lib.rlgan_deconv_fused_build_maps(d, mf.ctypes.data, None) == -1
     _lib.check(_lib.lib.rlgan_deconv_fused_build_maps(d, mf.ctypes.data, mb.ctypes.data))
     for m, size in ((mf, g.wff_floats), (mb, g.wfb_floats)):
         assert np.all(m[n:] == -1) and m[:n].min() >= 0 and m[:n].max() < size and np.unique(m[:n]).size == n
