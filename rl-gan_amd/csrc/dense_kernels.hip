@@ -78,6 +78,10 @@ __device__ __forceinline__ void tile_load_inside(f32x4 (&r)[2], const float* __r
                  : *(const f32x4*)(p + (size_t)(k0 + (u >> 4)) * ld + x0 + (u & 15) * 4);
   }
 }
+// Position of reduction index k in row x of an LDS tile: the row's eight 4-float groups are permuted by the row's
+// 16-row block (k ^ 0, 4, 8 or 12).  A 16-byte operand read stays one aligned group; the transposing store below,
+// whose sixteen x-quads per k would otherwise fall on four banks four deep, spreads over all 64 banks.
+__device__ __forceinline__ int swz(int x, int k) { return k ^ (((x >> 4) & 3) << 2); }
 // the registers of tile_load into an LDS tile [64 x][LDT], k contiguous
 template <bool KCONT>
 __device__ __forceinline__ void tile_store(float* t, const f32x4 (&r)[2]) {
@@ -85,11 +89,11 @@ __device__ __forceinline__ void tile_store(float* t, const f32x4 (&r)[2]) {
   for (int h = 0; h < 2; ++h) {
     const int u = threadIdx.x + 256 * h;
     if (KCONT) {
-      *(f32x4*)(t + (u >> 3) * LDT + (u & 7) * 4) = r[h];
+      *(f32x4*)(t + (u >> 3) * LDT + swz(u >> 3, (u & 7) * 4)) = r[h];
     } else {
-      const int k = u >> 4, x = (u & 15) * 4;
+      const int k = u >> 4, x = (u & 15) * 4;        // x .. x+3 lie in one 16-row block
 #pragma unroll
-      for (int i = 0; i < 4; ++i) t[(x + i) * LDT + k] = r[h][i];
+      for (int i = 0; i < 4; ++i) t[(x + i) * LDT + swz(x, k)] = r[h][i];
     }
   }
 }
@@ -140,8 +144,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
       f32x4 a[2], b[2];
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        a[s] = *(const f32x4*)(as + (wm + 16 * s + j) * LDT + 16 * kg + q4);
-        b[s] = *(const f32x4*)(bs + (wn + 16 * s + j) * LDT + 16 * kg + q4);
+        a[s] = *(const f32x4*)(as + (wm + 16 * s + j) * LDT + swz(wm + 16 * s, 16 * kg + q4));
+        b[s] = *(const f32x4*)(bs + (wn + 16 * s + j) * LDT + swz(wn + 16 * s, 16 * kg + q4));
       }
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
