@@ -187,6 +187,79 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvG g, const S sr
   }
 }
 
+// Forward pass of a first layer with four input channels and at most 47 patch elements (3x3 kernels) whose image
+// fits LDS: a workgroup stages one image with coalesced loads and gathers the patch quads from there (a quad is one
+// input pixel's four channels: one ds_read_b128 per k-group), the layer's six weight fragments stay in registers.
+// conv_fwd_kernel fetches every quad from memory, lanes 32 bytes apart, each input pixel about k*k/s*s times.
+template <int NT, class S>
+__global__ __launch_bounds__(256) void conv_fwd_c4_kernel(const ConvG g, const S src, const float* __restrict__ wfrag,
+                                                          float* __restrict__ y, int act_elu) {
+  extern __shared__ __attribute__((aligned(16))) float X[];      // [H * W][4]
+  constexpr int MAXG = 3, STAGE_U = 4;
+  const int lane = threadIdx.x & 63, wave = wave_id(), q = lane >> 4, j = lane & 15;
+  const int n = blockIdx.x, HW = g.H * g.W, npix = g.Ho * g.Wo;
+  const long long base = src.image(n);
+  for (int i0 = threadIdx.x; i0 < HW; i0 += 256 * STAGE_U) {
+    typename S::Raw raw[STAGE_U];
+#pragma unroll
+    for (int u = 0; u < STAGE_U; ++u) raw[u] = src.load(base, (size_t)4 * min(i0 + 256 * u, HW - 1));
+#pragma unroll
+    for (int u = 0; u < STAGE_U; ++u) {
+      const int i = i0 + 256 * u;
+      if (i < HW) *(f32x4*)(X + 4 * i) = src.value(raw[u], base);
+    }
+  }
+  f32x4 w[MAXG][NT];
+  int toff[MAXG];
+  float live[MAXG], one[MAXG];
+#pragma unroll
+  for (int gi = 0; gi < MAXG; ++gi) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) w[gi][t] = gi < g.NG ? *(const f32x4*)(wfrag + (gi * NT + t) * 256 + lane * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const int tap = 4 * gi + q, k0 = 4 * tap;               // this lane's quad of the group: one tap's four channels,
+    const bool data = k0 < g.K;                             // the bias row's constant 1, or the zeros after it
+    const int ky = data ? tap / g.k : 0, kx = data ? tap - ky * g.k : 0;
+    toff[gi] = (ky * g.W + kx) * 4;
+    live[gi] = data ? 1.f : 0.f;
+    one[gi] = k0 == g.K ? 1.f : 0.f;
+  }
+  __syncthreads();
+  float* yn = y + (size_t)n * npix * g.Cout;
+  for (int t = wave; t < (npix + 15) / 16; t += 4) {
+    const int p = min(16 * t + j, npix - 1), oy = fdiv(p, g.dWo), ox = p - oy * g.Wo;
+    const float* xp = X + ((g.s * oy) * g.W + g.s * ox) * 4;
+    f32x4 b[MAXG];
+#pragma unroll
+    for (int gi = 0; gi < MAXG; ++gi) {
+      b[gi] = *(const f32x4*)(xp + toff[gi]) * live[gi];
+      b[gi][0] += one[gi];
+    }
+    f32x4 acc[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int gi = 0; gi < MAXG; ++gi) {
+      if (gi < g.NG) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+#pragma unroll
+          for (int i = 0; i < NT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[gi][i][m], b[gi][m], acc[i], 0, 0, 0);
+        }
+      }
+    }
+    if (16 * t + j < npix) {
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        const int n0 = 16 * i + q * 4;
+        if (n0 >= g.Cout) continue;
+        f32x4 v = acc[i];
+        if (act_elu) v = f32x4{elu_f(v[0]), elu_f(v[1]), elu_f(v[2]), elu_f(v[3])};
+        *(f32x4*)(yn + (size_t)(16 * t + j) * g.Cout + n0) = v;
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------- dZ = dY * ELU'(Y)   (ELU' from the output: y > 0 ? 1 : y + 1)
 __global__ void elu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dz, size_t n) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1026,6 +1099,14 @@ int launch_fwd(const ConvG& g, const S& src, const float* wfrag, float* y, int n
   const long long Ml = (long long)n_images * g.Ho * g.Wo;
   if (Ml > 0x7fffffffll || ((uintptr_t)y & 15)) return RLGAN_E_ALIGN;
   const int M = (int)Ml;
+  if (g.Cin == 4 && g.NG <= 3 && g.NT <= 2 && (size_t)g.H * g.W * 16 <= 48 * 1024 && !((uintptr_t)wfrag & 15)) {
+    // a small first layer: one image per workgroup, staged in LDS
+    const size_t ilds = (size_t)g.H * g.W * 16;
+    hipStream_t st = (hipStream_t)stream;
+    if (g.NT == 1) hipLaunchKernelGGL((conv_fwd_c4_kernel<1, S>), dim3(n_images), dim3(256), ilds, st, g, src, wfrag, y, act_elu);
+    else hipLaunchKernelGGL((conv_fwd_c4_kernel<2, S>), dim3(n_images), dim3(256), ilds, st, g, src, wfrag, y, act_elu);
+    return launched();
+  }
   // workgroups per compute unit: as many as the LDS copies of the weights allow (eight at most: one wave per SIMD each)
   const size_t lds = (size_t)g.NG * g.NT * 1024 + (size_t)g.NG * 16;
   const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds));

@@ -2,7 +2,8 @@
 """The two pixel configurations of the reference as timed workloads at batch 4096, synthetic frames, random weights:
 
 * `conv_ddpg_doom_84_b4096` -- Conv_DDPG.py:82-87 on Conv_model.py:15-24,569-784: 84x84x4 float32 frames -> the
-  four-convolution "doom" head -> 64 features -> the 256-unit ELU layer -> critic.learn then actor.learn.
+  four-convolution "doom" head -> 64 features -> the 256-unit ELU layer -> critic.learn then actor.learn, replayed as
+  one HIP graph.
 * `pixel_curious_gan_universe_42_b4096` -- the learning iteration of Curious_GAN_mario.py:85-98 on 42x42x4 uint8
   frame stacks: index draw, generator step (decoder included), prediction, discriminator step, inverse model,
   critic and actor steps, replayed as one HIP graph.
@@ -53,14 +54,28 @@ def conv_ddpg_doom(B=4096, a_dim=6):
     a = torch.nn.functional.one_hot(torch.randint(0, a_dim, (B,), generator=g, device="cuda"), a_dim).float()
     r = torch.rand((B, 1), generator=g, device="cuda", dtype=torch.float32)
 
-    def step():
+    def body():
         # neither step trains the encoder (Conv_model.py:616,784), so the features of s serve both: two encoder passes per
         # update where the reference's two sess.run calls make three
         phis_n = enc.forward(s_n).clone()
         phis = enc.forward(s)
         critic.learn(None, a, r, None, phis=phis, phis_next=phis_n)
         actor.learn(None, critic, phis=phis)
-    return step
+
+    # the update is ~90 short launches: replayed as one HIP graph like the pixel Curious-GAN iteration (every counter and
+    # step size the kernels read lives on the device, so the replay is the same computation)
+    cur = torch.cuda.current_stream()
+    side = torch.cuda.Stream()
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            body()
+    cur.wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        body()
+    return graph.replay
 
 
 def pixel_curious_gan(B=4096, a_dim=6):
