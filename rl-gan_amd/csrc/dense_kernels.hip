@@ -35,7 +35,12 @@ struct GemmArgs {
 // One operand tile, 64 (x: rows of A / columns of B) by BK (k), as two float4 per thread.
 //   KCONT: memory is [x][k], a float4 holds four consecutive k of one x
 //   else:  memory is [k][x], a float4 holds four consecutive x of one k
-// Out-of-range elements read as 0, the ones index as 1 (operand A only: pass -1 otherwise).
+// Out-of-range elements read as 0, the ones index as 1 (operand A only: pass -1 otherwise).  This is the form for
+// tiles on an operand's border.  It has no branch around its loads either: every element is fetched from an address
+// clamped into the operand (four 4-byte loads, since neither the row end nor the alignment of a clamped address
+// allows a 16-byte one) and what lies outside is replaced afterwards.  With conditions around the loads a wave waits
+// for each of them where the branches join, and a product whose tiles are all border tiles (an output 4 to 16
+// columns wide) spent a memory latency per element group: 19-30 us for layers of a few thousand multiply-adds per row.
 template <bool KCONT>
 __device__ __forceinline__ void tile_load(f32x4 (&r)[2], const float* __restrict__ p, int ld, int x0, int k0, int nx, int nk,
                                           int ones_x, int ones_k) {
@@ -45,23 +50,25 @@ __device__ __forceinline__ void tile_load(f32x4 (&r)[2], const float* __restrict
     int x, k;
     if (KCONT) { x = x0 + (u >> 3); k = k0 + (u & 7) * 4; }
     else       { k = k0 + (u >> 4); x = x0 + (u & 15) * 4; }
-    f32x4 v{0.f, 0.f, 0.f, 0.f};
+    f32x4 v;
     if (KCONT) {
-      if (x < nx && k + 3 < nk) v = *(const f32x4*)(p + (size_t)x * ld + k);
-      else if (x < nx) {
+      const float* row = p + (size_t)min(x, nx - 1) * ld;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) if (k + i < nk) v[i] = p[(size_t)x * ld + k + i];
+      for (int i = 0; i < 4; ++i) v[i] = row[min(k + i, nk - 1)];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (x >= nx || k + i >= nk) v[i] = 0.f;
+        if (k + i == ones_k || x == ones_x) v[i] = 1.f;
       }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) if (k + i == ones_k || x == ones_x) v[i] = 1.f;
     } else {
-      if (k < nk && x + 3 < nx) v = *(const f32x4*)(p + (size_t)k * ld + x);
-      else if (k < nk) {
+      const float* row = p + (size_t)min(k, nk - 1) * ld;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) if (x + i < nx) v[i] = p[(size_t)k * ld + x + i];
+      for (int i = 0; i < 4; ++i) v[i] = row[min(x + i, nx - 1)];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (k >= nk || x + i >= nx) v[i] = 0.f;
+        if (x + i == ones_x || k == ones_k) v[i] = 1.f;
       }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) if (x + i == ones_x || k == ones_k) v[i] = 1.f;
     }
     r[h] = v;
   }
@@ -174,9 +181,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
     stash(kt + 1);
     __syncthreads();
   }
-  for (; kt < nkt; ++kt) {              // the edge steps (and everything, for a tile on the operands' border)
+  for (; kt < nkt; ++kt) {              // the edge steps (and everything, for a tile on the operands' border): same pipeline
     if (kt + 1 < nkt) load(kt + 1, false);
+    __builtin_amdgcn_sched_barrier(0);
     multiply(kt);
+    __builtin_amdgcn_sched_barrier(0);
     if (kt + 1 < nkt) stash(kt + 1);
     __syncthreads();
   }
@@ -207,8 +216,15 @@ __global__ __launch_bounds__(256) void split_sum_kernel(const float* __restrict_
                                                         float* __restrict__ c, int ldc, int act) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= (size_t)M * N) return;
+  // slab order, eight loads in flight at a time (one load per addition is a chain of memory latencies)
   float v = 0.f;
-  for (int z = 0; z < n_slabs; ++z) v += slabs[z * slab + i];
+  for (int z0 = 0; z0 < n_slabs; z0 += 8) {
+    float t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = slabs[(size_t)min(z0 + u, n_slabs - 1) * slab + i];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) if (z0 + u < n_slabs) v += t[u];
+  }
   if (act == 1) v = v > 0.f ? v : expm1f(v);
   else if (act == 2) v = fmaxf(v, 0.f);
   else if (act == 3) v = __builtin_amdgcn_fmed3f(v, 0.f, 6.f);
