@@ -462,6 +462,41 @@ int rlgan_column_sums_noalloc(const float* dy, const float* y_relu, int64_t rows
 /* dst[i] = map[i] >= 0 ? src[map[i]] : 0   (a gradient image back into canonical parameter order) */
 int rlgan_gather_map(const float* src, const int32_t* map, int32_t n, float* dst, void* stream);
 
+/* ---- actor and critic of the pixel variant as row passes (Conv_model.py:569-784) ------------------------------------
+ * Network kinds 4 (actor) and 5 (critic) of rlgan_geometry / rlgan_build_maps / rlgan_weight_grads: s_dim = 256, the
+ * encoder's features; a_dim = the action columns padded to a multiple of 4 (4 .. 12).  Canonical order = the four
+ * layers' blocks one after the other, each the [K, N] kernel then the bias: actor 256x200, 200x200, 200x12, 12xa_pad;
+ * critic (256 + a_pad)x200 (rows: features, then action columns), 200x200, 200x12, 12x4 (q is output column 0); the
+ * padding columns hold zero weights and receive zero gradients.  relu6 after the first three layers, tanh on the
+ * actor's output.  The x0 work array of these kinds is 272 columns wide.
+ *
+ * rlgan_pixel_critic_step_rows (Conv_model.py:610-616,653-663): a' = actor_target(phis'), q' = critic_target(phis', a'),
+ * q = critic_eval(phis, a), loss = mean((q - (r + gamma q'))^2), backward through critic_eval; loss_parts[tile] =
+ * the tile's sum of squared errors (the loss is their sum / n_rows).  a: [n_rows][>= a_cols], its first a_cols
+ * columns are the action; r: [n_rows].  counter (optional) += 1.
+ * rlgan_pixel_actor_step_rows (Conv_model.py:619,746-754,778-784): a = actor_eval(phis), dq/da through critic_eval with
+ * d(sum_b q_b) = 1, backward through actor_eval.
+ * Afterwards: rlgan_weight_grads on the filled work arrays, then rlgan_apply. */
+typedef struct {
+  int32_t a_pad, a_cols, n_rows;
+  rlgan_net_t critic_eval, critic_target, actor_target;
+  rlgan_mat_t phis, phis_next, a;
+  const float* r;
+  float gamma;
+  rlgan_acts_t acts_critic;
+  float* loss_parts;
+  int32_t* counter;
+} rlgan_pixel_critic_step_t;
+typedef struct {
+  int32_t a_pad, n_rows;
+  rlgan_net_t actor_eval, critic_eval;
+  rlgan_mat_t phis;
+  rlgan_acts_t acts_actor;
+  int32_t* counter;
+} rlgan_pixel_actor_step_t;
+int rlgan_pixel_critic_step_rows(const rlgan_pixel_critic_step_t* step, void* stream);
+int rlgan_pixel_actor_step_rows(const rlgan_pixel_actor_step_t* step, void* stream);
+
 /* ---- the same layers without the cols matrix in memory (dec_deconv3 and dec_deconv4, Conv_model.py:468-473) ----
  * Two stride-2 shapes run as fused kernels: 8x8x64 -> 19x19x32 with a 5x5 kernel (kind 1) and 19x19x32 -> 42x42x1
  * with a 6x6 kernel (kind 2); 3x3x128 -> 8x8x64 with a 4x4 kernel (dec_deconv2, Conv_model.py:463) has a fused FORWARD

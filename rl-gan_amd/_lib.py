@@ -13,7 +13,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librlgan_amd.so")
 
 NET_ACTOR, NET_CRITIC, NET_GENERATOR, NET_DISCRIMINATOR = 0, 1, 2, 3
-KIND_NAMES = {NET_ACTOR: "actor", NET_CRITIC: "critic", NET_GENERATOR: "generator", NET_DISCRIMINATOR: "discriminator"}
+NET_PIXEL_ACTOR, NET_PIXEL_CRITIC = 4, 5                         # actor / critic of the pixel variant on 256 encoder features
+KIND_NAMES = {NET_ACTOR: "actor", NET_CRITIC: "critic", NET_GENERATOR: "generator", NET_DISCRIMINATOR: "discriminator",
+              NET_PIXEL_ACTOR: "pixel actor", NET_PIXEL_CRITIC: "pixel critic"}
 
 
 class Geom(C.Structure):
@@ -65,6 +67,18 @@ class GenStep(C.Structure):
     _fields_ = [("s_dim", _i32), ("a_dim", _i32), ("n_rows", _i32), ("gen", Net), ("disc", Net),
                 ("s", Mat), ("a", Mat), ("inv_global_batch", C.c_float), ("acts_gen", Acts), ("loss_parts", _fp),
                 ("row_idx", _fp), ("counter", _fp)]
+
+
+class PixelCriticStep(C.Structure):
+    _fields_ = [("a_pad", _i32), ("a_cols", _i32), ("n_rows", _i32),
+                ("critic_eval", Net), ("critic_target", Net), ("actor_target", Net),
+                ("phis", Mat), ("phis_next", Mat), ("a", Mat), ("r", _fp), ("gamma", C.c_float),
+                ("acts_critic", Acts), ("loss_parts", _fp), ("counter", _fp)]
+
+
+class PixelActorStep(C.Structure):
+    _fields_ = [("a_pad", _i32), ("n_rows", _i32), ("actor_eval", Net), ("critic_eval", Net), ("phis", Mat),
+                ("acts_actor", Acts), ("counter", _fp)]
 
 
 class Eval(C.Structure):
@@ -151,6 +165,8 @@ PROTOTYPES = {
     "rlgan_actor_step_rows": [C.POINTER(ActorStep), _vp],
     "rlgan_disc_step_rows": [C.POINTER(DiscStep), _vp],
     "rlgan_gen_step_rows": [C.POINTER(GenStep), _vp],
+    "rlgan_pixel_critic_step_rows": [C.POINTER(PixelCriticStep), _vp],
+    "rlgan_pixel_actor_step_rows": [C.POINTER(PixelActorStep), _vp],
     "rlgan_phase1_rows": [C.POINTER(CriticStep), C.POINTER(DiscStep), _vp],
     "rlgan_phase2_rows": [C.POINTER(ActorStep), C.POINTER(GenStep), _vp],
     "rlgan_gan_eval_rows": [C.POINTER(Eval), _vp, _vp],

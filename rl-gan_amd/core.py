@@ -70,6 +70,14 @@ def tensor_table(kind: int, s_dim: int, a_dim: int) -> Tuple[List[Tuple[str, Tup
         return ([("l1/w1_G", (s_dim, H)), ("l1/w1_s", (s_dim, H)), ("l1/w1_a", (a_dim, H)), ("l1/b1", (1, H)),
                  ("l2/kernel", (H, H)), ("l2/bias", (H,)), ("l3/kernel", (H, 10)), ("l3/bias", (10,)),
                  ("D/w3", (10, 1)), ("D/b3", (1, 1))], (0.001,) * 4)
+    if kind == _lib.NET_PIXEL_ACTOR:    # Conv_model.py:713-739; a_dim here = the action columns padded to a multiple of 4
+        return ([("l1/kernel", (s_dim, H)), ("l1/bias", (H,)), ("l2/kernel", (H, H)), ("l2/bias", (H,)),
+                 ("l3/kernel", (H, 12)), ("l3/bias", (12,)), ("a/kernel", (12, a_dim)), ("a/bias", (a_dim,))],
+                (0.001, 0.001, 0.001, 0.0))
+    if kind == _lib.NET_PIXEL_CRITIC:   # Conv_model.py:623-650; w1_s and w1_a as one block, q in column 0 of four
+        return ([("l1/w1", (s_dim + a_dim, H)), ("l1/b1", (H,)), ("l2/kernel", (H, H)), ("l2/bias", (H,)),
+                 ("l3/kernel", (H, 12)), ("l3/bias", (12,)), ("q/kernel", (12, 4)), ("q/bias", (4,))],
+                (0.01, 0.01, 0.01, 0.01))
     raise ValueError(kind)
 
 
@@ -162,7 +170,8 @@ class Workspace:
         self.rows = rows
         g = net.geom
         f = lambda w: torch.zeros(rows * w, dtype=torch.float32, device=dev)
-        self.x0, self.h1, self.h2, self.h3 = f(32), f(208), f(208), f(g.ld3)
+        x0_cols = 272 if net.kind >= _lib.NET_PIXEL_ACTOR else 32
+        self.x0, self.h1, self.h2, self.h3 = f(x0_cols), f(208), f(208), f(g.ld3)
         self.dz1, self.dz2, self.dz3, self.dz4 = f(208), f(208), f(g.ld3), f(16)
         self.chunk_rows, self.n_chunks = _lib.wgrad_chunks(rows)
         self.gslabs = torch.zeros(self.n_chunks * g.gpad_floats, dtype=torch.float32, device=dev)

@@ -49,7 +49,7 @@ const char* rlgan_error_string(int code) {
 
 int rlgan_geometry(int kind, int s_dim, int a_dim, rlgan_geom_t* out) {
   if (!out) return RLGAN_E_ARG;
-  if (kind < 0 || kind > 3) return RLGAN_E_KIND;
+  if (kind < 0 || kind > NET_PCRITIC) return RLGAN_E_KIND;
   Geo g;
   if (!make_geo(kind, s_dim, a_dim, g)) return RLGAN_E_DIMS;
   out->n_params = g.n_params; out->wf_floats = g.wf_floats; out->wb_floats = g.wb_floats;
@@ -61,12 +61,14 @@ int rlgan_geometry(int kind, int s_dim, int a_dim, rlgan_geom_t* out) {
 // 114-134).  Input-tile column order: actor [s], critic/generator [s, a], discriminator [s, x, a].
 int rlgan_build_maps(int kind, int s_dim, int a_dim, int32_t* map_f, int32_t* map_b, int32_t* map_g) {
   if (!map_f || !map_g) return RLGAN_E_ARG;
-  if (kind < 0 || kind > 3) return RLGAN_E_KIND;
+  if (kind < 0 || kind > NET_PCRITIC) return RLGAN_E_KIND;
   Geo g;
   if (!make_geo(kind, s_dim, a_dim, g)) return RLGAN_E_DIMS;
   MapOut m{map_f, map_b, map_g, 0, &g};
   const int S = s_dim, A = a_dim;
   switch (kind) {
+    case NET_PACTOR:
+    case NET_PCRITIC: emit_weight(m, 0, 0, g.K0); break;                               // one [K0, 200] block: features, then action columns
     case NET_ACTOR:  emit_weight(m, 0, 0, S); break;                                   // l1/kernel
     case NET_CRITIC:
     case NET_GEN:    emit_weight(m, 0, 0, S); emit_weight(m, 0, S, A); break;           // w1_s, w1_a

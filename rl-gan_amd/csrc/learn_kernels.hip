@@ -789,14 +789,14 @@ int rlgan_weight_grads(const rlgan_wgrad_job_t* jobs, int n_jobs, int s_dim, int
   for (int ji = 0; ji < n_jobs; ++ji) {
     const rlgan_wgrad_job_t& J = jobs[ji];
     Geo g;
-    if (J.kind < 0 || J.kind > 3) return RLGAN_E_KIND;
+    if (J.kind < 0 || J.kind > NET_PCRITIC) return RLGAN_E_KIND;
     if (!make_geo(J.kind, s_dim, a_dim, g)) return RLGAN_E_DIMS;
     if (!acts_ok(J.acts) || !J.gslabs) return RLGAN_E_ARG;
     int32_t cr, nc;
     if (const int rc = rlgan_wgrad_chunks(J.rows, &cr, &nc)) return rc;
     const float* X[4] = {J.acts.x0, J.acts.h1, J.acts.h2, J.acts.h3};
     const float* Z[4] = {J.acts.dz1, J.acts.dz2, J.acts.dz3, J.acts.dz4};
-    const int ldx[4] = {X0_COLS, NP_H, NP_H, g.ld3};
+    const int ldx[4] = {x0_cols(J.kind), NP_H, NP_H, g.ld3};
     const int ldz[4] = {NP_H, NP_H, g.ld3, 16};
     for (int l = 0; l < 4; ++l) {
       WItem& it = A.it[A.n_items++];

@@ -20,7 +20,11 @@ namespace rlgan {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 enum { ACT_LINEAR = 0, ACT_RELU = 1, ACT_RELU6 = 2, ACT_LRELU = 3, ACT_TANH = 4 };
-enum { NET_ACTOR = 0, NET_CRITIC = 1, NET_GEN = 2, NET_DISC = 3 };
+// 0-3: the networks of the arm variant.  4, 5: actor and critic of the pixel variant on the 256 features of the state
+// encoder (Conv_model.py:621-651,711-744): the same 200-200-10 body, a first layer of 17 k-groups instead of one.
+enum { NET_ACTOR = 0, NET_CRITIC = 1, NET_GEN = 2, NET_DISC = 3, NET_PACTOR = 4, NET_PCRITIC = 5 };
+constexpr int PIX_FEATURES = 256;   // Conv_model.py:24: the encoders' 256-unit layer
+constexpr int PIX_N3 = 12;          // the 10-unit layer kept 12 wide (16-byte rows of the layer-wise parameter blocks)
 
 constexpr int HID = 200;        // DDPG.py:82,159 ; Curious_GAN.py:59,121
 constexpr int NT_H = 13;        // 16-wide column tiles of a hidden layer
@@ -29,6 +33,8 @@ constexpr int NP_H = 208;       // padded hidden width (global work arrays)
 // 16 rows a ds_read_b128 lane group touches fall on 16 disjoint 4-bank slots of the 64 banks
 constexpr int LD_W = 212;       // wide activation tile (208 columns)
 constexpr int LD_X0 = 36;       // network-input tile (32 columns)
+constexpr int XW_COLS = 272;    // input columns of the pixel networks: 256 features, up to 15 action columns, the constant 1
+constexpr int LD_XW = 276;      // their LDS row stride
 constexpr int LD_O = 20;        // 16-column tile
 constexpr int LDP = 20;         // row stride of a 16x16 partial-sum tile
 constexpr int LD_3W = 68;       // 64-column tile
@@ -49,7 +55,9 @@ struct Geo {
 
 __host__ __device__ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
-__host__ __device__ constexpr int first_groups(int kind) { return kind == NET_DISC ? 2 : 1; }
+__host__ __device__ constexpr int first_groups(int kind) { return kind >= NET_PACTOR ? XW_COLS / 16 : kind == NET_DISC ? 2 : 1; }
+__host__ __device__ constexpr int x0_cols(int kind) { return kind >= NET_PACTOR ? XW_COLS : 32; }    // global x0 work array
+__host__ __device__ constexpr int x0_ld(int kind) { return kind >= NET_PACTOR ? LD_XW : LD_X0; }      // LDS input tile
 
 __host__ __device__ inline bool make_geo(int kind, int S, int A, Geo& g) {
   if (S < 1 || A < 1) return false;
@@ -59,12 +67,17 @@ __host__ __device__ inline bool make_geo(int kind, int S, int A, Geo& g) {
     case NET_CRITIC: g.K0 = S + A;     g.N3 = 10; g.NOUT = 1; break;
     case NET_GEN:    g.K0 = S + A;     g.N3 = 50; g.NOUT = S; break;
     case NET_DISC:   g.K0 = 2 * S + A; g.N3 = 10; g.NOUT = 1; break;
+    // pixel variant: S = 256 features; A = the action columns, a multiple of 4 (the layer-wise parameter blocks keep
+    // 16-byte rows: their padding columns hold zero weights); the critic's q is column 0 of a 4-wide output
+    case NET_PACTOR:  g.K0 = S;     g.N3 = PIX_N3; g.NOUT = A; break;
+    case NET_PCRITIC: g.K0 = S + A; g.N3 = PIX_N3; g.NOUT = 4; break;
     default: return false;
   }
+  if (kind >= NET_PACTOR && (S != PIX_FEATURES || A < 4 || A > 12 || A % 4 != 0)) return false;
   // first layer: inputs plus the constant-1 column in one k-group of 16, two for the discriminator
   // (its 2S + A = 16 inputs fill a group by themselves)
   const int ng1 = first_groups(kind);
-  if (g.K0 + 1 > 16 * ng1 || g.K0 > 16 || g.NOUT > 15) return false;
+  if (g.K0 + 1 > 16 * ng1 || (kind < NET_PACTOR && g.K0 > 16) || g.NOUT > 15) return false;
   g.NT3 = cdiv(g.N3, 16);
   g.K[0] = g.K0; g.N[0] = HID; g.K[1] = HID; g.N[1] = HID; g.K[2] = HID; g.N[2] = g.N3; g.K[3] = g.N3; g.N[3] = g.NOUT;
   int of = 0, ob = 0, og = 0, np_ = 0;
@@ -132,6 +145,8 @@ template <> struct NetT<NET_ACTOR>  { static constexpr int A1 = ACT_RELU6, A2 = 
 template <> struct NetT<NET_CRITIC> { static constexpr int A1 = ACT_RELU6, A2 = ACT_RELU6, A3 = ACT_RELU,  A4 = ACT_LINEAR, NT3 = 1, L3 = 20; };
 template <> struct NetT<NET_GEN>    { static constexpr int A1 = ACT_RELU,  A2 = ACT_RELU,  A3 = ACT_RELU,  A4 = ACT_LINEAR, NT3 = 4, L3 = 68; };
 template <> struct NetT<NET_DISC>   { static constexpr int A1 = ACT_LRELU, A2 = ACT_LRELU, A3 = ACT_LRELU, A4 = ACT_LINEAR, NT3 = 1, L3 = 20; };
+template <> struct NetT<NET_PACTOR>  { static constexpr int A1 = ACT_RELU6, A2 = ACT_RELU6, A3 = ACT_RELU6, A4 = ACT_TANH,   NT3 = 1, L3 = 20; };
+template <> struct NetT<NET_PCRITIC> { static constexpr int A1 = ACT_RELU6, A2 = ACT_RELU6, A3 = ACT_RELU6, A4 = ACT_LINEAR, NT3 = 1, L3 = 20; };
 
 // ---------------------------------------------------------------- LDS carve (floats)
 
@@ -141,6 +156,7 @@ constexpr int PART_FLOATS = (CHAIN_SLOTS + 4) * ROWS * LDP;
 constexpr int WIDE_FLOATS = ROWS * LD_W;
 constexpr int T3_FLOATS = ROWS * LD_3W;              // h3 tile (16 or 64 columns)
 constexpr int X0_FLOATS = ROWS * LD_X0;
+constexpr int XW_FLOATS = ROWS * LD_XW;
 constexpr int O_FLOATS = ROWS * LD_O;
 #ifndef RLGAN_GD
 #define RLGAN_GD 2
@@ -406,12 +422,14 @@ struct Chain {
   f32x4 wlast;                                         // ... and of its last k-group (LAST only)
   float* part;                                         // [CHAIN_SLOTS][16][LDP]
   // wn: fragment image of the narrow layer (one column tile); ng: its number of k-groups
-  __device__ __forceinline__ void issue(const float* __restrict__ wn, int ng, int w) {
+  //     nt, tile: the narrow "layer" may also be ONE column tile of a layer with nt tiles per k-group (the action columns
+  //     of the pixel critic's input gradient)
+  __device__ __forceinline__ void issue(const float* __restrict__ wn, int ng, int w, int nt = 1, int tile = 0) {
     FragSrc src;
-    src.set(wn, 0);
+    src.set(wn, tile);
 #pragma unroll
-    for (int i = 0; i < TMAX; ++i) wc[i] = src.load(min(w + 4 * i, ng - 1));
-    if constexpr (LAST) wlast = src.load(ng - 1);
+    for (int i = 0; i < TMAX; ++i) wc[i] = src.load(min(w + 4 * i, ng - 1) * nt);
+    if constexpr (LAST) wlast = src.load((ng - 1) * nt);
   }
   // the last k-group's product from the completed tile at column 16*(ng-1) of xs, into slot 4 (one wave calls this)
   __device__ __forceinline__ void run_last(const float* xs, int ldx, int ng) {
@@ -566,11 +584,11 @@ __device__ __forceinline__ void net_forward(const float* __restrict__ wf, const 
   const int lane = threadIdx.x & 63;
   const int n3 = g.N3, nout = g.NOUT;
   Pre<NT_H, NT_H> p2;
-  dense16(p1, t.x0, LD_X0, NoPre{}, [=](int r, int c, float z, float) {
+  dense16(p1, t.x0, x0_ld(KIND), NoPre{}, [=](int r, int c, float z, float) {
     const float v = c < HID ? act_f<N::A1>(z) : (c == HID ? 1.f : 0.f);
     h1[r * LD_W + c] = v;
     return v;
-  }, STORE ? ws.h1 : nullptr, [&] { p2.issue(wf + g.offf[1]); });
+  }, STORE ? ws.h1 : nullptr, [&] { p2.issue(wf + g.offf[1]); }, t.part + SPART_OFF);   // the pixel networks' 17 k-groups share the last tile
   auto f2 = [=](int r, int c, float z, float) {
     const float v = c < HID ? act_f<N::A2>(z) : (c == HID ? 1.f : 0.f);
     h2[r * LD_W + c] = v;
@@ -696,7 +714,9 @@ __device__ __forceinline__ void net_backward(const float* __restrict__ wb, const
     using Q2 = Pre<NT_H, NT_H>;
     Chain<Q2::TMAX, Q2::SPLIT> ch;
     ch.part = t.part;
-    dense16(p2, h2, LD_W, g1, f1, STORE ? ws.dz1 : nullptr, [&] { ch.issue(wb + g.offb[0], NT_H, p2.w); }, ch, h1, LD_W,
+    // the arm networks have one tile of inputs; of the pixel critic's 17 only the last, which holds the action, is wanted
+    const int xt = KIND >= NET_PACTOR ? g.ntb[0] - 1 : 0;
+    dense16(p2, h2, LD_W, g1, f1, STORE ? ws.dz1 : nullptr, [&] { ch.issue(wb + g.offb[0], NT_H, p2.w, g.ntb[0], xt); }, ch, h1, LD_W,
             t.part + SPART_OFF);
     next();
     if constexpr (Q2::SPLIT) {
@@ -705,7 +725,7 @@ __device__ __forceinline__ void net_backward(const float* __restrict__ wb, const
     }
     {
       const int r = threadIdx.x >> 4, c = threadIdx.x & 15;
-      x0[r * LD_X0 + c] = Q2::SPLIT ? chain_sum1_last(t.part, r, c) : chain_sum1(t.part, r, c);
+      x0[r * x0_ld(KIND) + 16 * xt + c] = Q2::SPLIT ? chain_sum1_last(t.part, r, c) : chain_sum1(t.part, r, c);
     }
     lds_barrier();
   } else {
@@ -741,9 +761,40 @@ __device__ __forceinline__ void load_x0(float* x0, int row0, int n_rows, MatIn b
   }
 }
 
-__device__ __forceinline__ ActsG acts_at(const float* const* p8, int row0, int ld3) {
+// Input tile of the pixel networks, [16][LD_XW]: 256 features (rows of a dense matrix), then `aw` action columns (from
+// a matrix in memory or from an LDS tile of stride lda), the constant 1, zeros up to XW_COLS; rows at or beyond
+// n_rows are zero.  Optionally mirrored to the global x0 work array ([4 row blocks][XW_COLS][4 rows] per tile, after a
+// workgroup barrier of its own).
+//   a: aw columns are read (rows of a matrix in memory, or of an LDS tile when a_local), columns aw .. ap-1 are zero
+//   (the parameter blocks' padding), column ap holds the constant 1
+__device__ __forceinline__ void load_xw(float* x0, int row0, int n_rows, const float* __restrict__ phis, int ldp,
+                                        const float* a, int lda, int a_local, int aw, int ap, float* x0_global) {
+  for (int e = threadIdx.x; e < ROWS * (PIX_FEATURES / 4); e += THREADS) {
+    const int r = e / (PIX_FEATURES / 4), c4 = e - r * (PIX_FEATURES / 4), gr = row0 + r;
+    f32x4 v{0.f, 0.f, 0.f, 0.f};
+    if (gr < n_rows) v = *(const f32x4*)(phis + (size_t)gr * ldp + 4 * c4);
+    *(f32x4*)(x0 + r * LD_XW + 4 * c4) = v;
+  }
+  {
+    const int r = threadIdx.x >> 4, c = threadIdx.x & 15, gr = row0 + r;
+    float v = 0.f;
+    if (c < aw && gr < n_rows) v = a_local ? a[r * lda + c] : a[(size_t)gr * lda + c];
+    if (c == ap) v = 1.f;
+    x0[r * LD_XW + PIX_FEATURES + c] = v;
+  }
+  if (x0_global) {
+    lds_barrier();
+    for (int e = threadIdx.x; e < 4 * XW_COLS; e += THREADS) {
+      const int b = e / XW_COLS, c = e - b * XW_COLS;
+      const float* xp = x0 + (4 * b) * LD_XW + c;
+      *(f32x4*)(x0_global + work_off(XW_COLS, 4 * b, c)) = f32x4{xp[0], xp[LD_XW], xp[2 * LD_XW], xp[3 * LD_XW]};
+    }
+  }
+}
+
+__device__ __forceinline__ ActsG acts_at(const float* const* p8, int row0, int ld3, int x0c = X0_COLS) {
   ActsG a;
-  a.x0 = (float*)p8[0] + (size_t)row0 * X0_COLS;
+  a.x0 = (float*)p8[0] + (size_t)row0 * x0c;
   a.h1 = (float*)p8[1] + (size_t)row0 * NP_H;
   a.h2 = (float*)p8[2] + (size_t)row0 * NP_H;
   a.h3 = (float*)p8[3] + (size_t)row0 * ld3;

@@ -19,10 +19,13 @@ from typing import Dict, List, Optional
 import numpy as np
 import torch
 
+import ctypes as C
+
 from . import _lib
 from ._lib import check, lib
 from .conv import ConvEncoder, DenseLayer
-from .core import _stream, device, launch_apply, row_ld
+from .core import (DeviceNet, Workspace, _stream, device, launch_apply, launch_wgrads, mat, reduce_job, rmsprop_job, row_ld, rows16,
+                   wgrad_job)
 
 N_L1, N_L2, N_L3, L3_PAD = 200, 200, 10, 12                     # Conv_model.py:627,636,643 / :716,723,730
 
@@ -89,6 +92,37 @@ class _Net:
         return d
 
 
+class _RowNet:
+    """The four layers of one network as ONE flat parameter vector with the fragment images the row-pass kernels read
+    (`DeviceNet`, kinds 4 / 5 of the library).  The layers' `canon` and `grad` become views into the flat vectors, so
+    the layer-wise calls (acting, the tests' accessors, checkpoints) and the row passes see the same numbers."""
+
+    def __init__(self, kind: int, a_pad: int, net: _Net, trainable: bool):
+        flat = torch.cat([L.canon for L in net.layers]).cpu().numpy()
+        self.dn = DeviceNet(kind, 256, a_pad, trainable=trainable, init=flat)
+        self.grad = torch.zeros_like(self.dn.canon)
+        o = 0
+        for L in net.layers:
+            L.canon, L.grad = self.dn.canon[o:o + L.n_params], self.grad[o:o + L.n_params]
+            o += L.n_params
+        assert o == self.dn.n_params
+        self._ws = {}
+
+    def workspace(self, rows: int) -> Workspace:
+        if rows not in self._ws:
+            self._ws[rows] = Workspace(self.dn, rows)
+        return self._ws[rows]
+
+    def repack(self) -> None:
+        """After the flat vector was written from outside (a checkpoint): refresh the fragment images."""
+        self.dn.repack()
+
+
+def row_passes_fit(h_dim: int, a_pad: int) -> bool:
+    """The row-pass kernels are built for the encoders' 256 features and 4 .. 12 (padded) action columns."""
+    return h_dim == 256 and 4 <= a_pad <= 12
+
+
 class LSTMUnit:
     """`lstm_unit` (Conv_model.py:67-99): one step of tf.contrib.rnn.BasicLSTMCell(n_lstm_unit) on the state encoder's
     features, state (c, h) in and out.  With USE_LSTM False (Conv_model.py:667) the loop only carries this state along and
@@ -150,7 +184,19 @@ class PixelActor:
         self.eval_net = self._build(rng, params)
         self.target_net = self._build(rng, target_params)
         self.t_replace_counter = torch.zeros(1, dtype=torch.int32, device=device())
+        # learn() as row passes over 16-row tiles (one launch for the step, one for the weight gradients, one for the
+        # optimizer) where the shapes fit; `row_passes = False` keeps the layer-by-layer products
+        self.row_passes = row_passes_fit(self.h_dim, self.a_pad)
+        if self.row_passes:
+            self._rn = _RowNet(_lib.NET_PIXEL_ACTOR, self.a_pad, self.eval_net, True)
+            self._rn_t = _RowNet(_lib.NET_PIXEL_ACTOR, self.a_pad, self.target_net, False)
+            self._ms = torch.ones_like(self._rn.dn.canon)
         self._opt = [_RMSProp(e, t) for e, t in zip(self.eval_net.layers, self.target_net.layers)]
+        if self.row_passes:                                      # the layers' slots are views of the flat one
+            o = 0
+            for opt in self._opt:
+                opt.ms = self._ms[o:o + opt.layer.n_params]
+                o += opt.layer.n_params
         self._acts: Optional[List[torch.Tensor]] = None
         self.LSTM_unit = LSTMUnit(state_encoder, rng=rng)        # Conv_model.py:685-686,693-694
         self.LSTM_unit_ = LSTMUnit(state_encoder, rng=rng)
@@ -198,6 +244,29 @@ class PixelActor:
         phis: features of `s` when the caller already holds them."""
         if phis is None:
             phis = self.state_encoder.forward(s)
+        if self.row_passes and critic.row_passes:
+            self._learn_rows(phis.contiguous(), critic)
+        else:
+            self._learn_layers(phis, critic)
+        # e_params / t_params are collected by scope (Conv_model.py:708-709), so the periodic tf.assign list also copies
+        # the eval net's LSTM cell into the target's (Conv_model.py:752-753) although no optimizer touches either
+        e, t = self.LSTM_unit.cell, self.LSTM_unit_.cell
+        check(lib.rlgan_target_update(t.canon.data_ptr(), e.canon.data_ptr(), e.n_params, 1.0, self.t_replace_counter.data_ptr(),
+                                      self.t_replace_iter, None, None, _stream()), "rlgan_target_update")
+
+    def _learn_rows(self, phis: torch.Tensor, critic: "PixelCritic") -> None:
+        n = phis.shape[0]
+        ws = self._rn.workspace(rows16(n))
+        step = _lib.PixelActorStep(self.a_pad, n, self._rn.dn.net(True), critic._rn.dn.net(True), mat(phis), ws.acts(),
+                                   self.t_replace_counter.data_ptr())
+        check(lib.rlgan_pixel_actor_step_rows(C.byref(step), _stream()), "rlgan_pixel_actor_step_rows")
+        launch_wgrads([wgrad_job(self._rn.dn, ws)], 256, self.a_pad)
+        red = reduce_job(self._rn.dn, ws)
+        red.grad = self._rn.grad.data_ptr()
+        launch_apply([rmsprop_job(self._rn.dn, self._rn.grad, self._ms, -self.lr, target=self._rn_t.dn, counter=self.t_replace_counter,
+                                  period=self.t_replace_iter)], reduces=[red])
+
+    def _learn_layers(self, phis: torch.Tensor, critic: "PixelCritic") -> None:
         a = self.actions(phis)
         cacts = critic.eval_net.forward(critic._rows(phis, a))
         dq = torch.ones_like(cacts[-1])
@@ -209,11 +278,9 @@ class PixelActor:
         self.eval_net.backward(self._acts, da, need_dx=False)
         self.t_replace_counter.add_(1)
         launch_apply([o.job(-self.lr, self.t_replace_counter, self.t_replace_iter) for o in self._opt])
-        # e_params / t_params are collected by scope (Conv_model.py:708-709), so the periodic tf.assign list also copies
-        # the eval net's LSTM cell into the target's (Conv_model.py:752-753) although no optimizer touches either
-        e, t = self.LSTM_unit.cell, self.LSTM_unit_.cell
-        check(lib.rlgan_target_update(t.canon.data_ptr(), e.canon.data_ptr(), e.n_params, 1.0, self.t_replace_counter.data_ptr(),
-                                      self.t_replace_iter, None, None, _stream()), "rlgan_target_update")
+        if self.row_passes:                                      # the row-pass kernels read the fragment images
+            self._rn.repack()
+            self._rn_t.repack()
 
 
 class PixelCritic:
@@ -229,7 +296,17 @@ class PixelCritic:
         self.target_net = self._build(rng, target_params)
         self.t_replace_counter = torch.zeros(1, dtype=torch.int32, device=device())
         self.loss_out = torch.zeros(1, dtype=torch.float32, device=device())
+        self.row_passes = row_passes_fit(self.h_dim, self.a_pad) and actor.row_passes
+        if self.row_passes:
+            self._rn = _RowNet(_lib.NET_PIXEL_CRITIC, self.a_pad, self.eval_net, True)
+            self._rn_t = _RowNet(_lib.NET_PIXEL_CRITIC, self.a_pad, self.target_net, False)
+            self._ms = torch.ones_like(self._rn.dn.canon)
         self._opt = [_RMSProp(e, t) for e, t in zip(self.eval_net.layers, self.target_net.layers)]
+        if self.row_passes:
+            o = 0
+            for opt in self._opt:
+                opt.ms = self._ms[o:o + opt.layer.n_params]
+                o += opt.layer.n_params
         self._parts: Optional[torch.Tensor] = None
 
     def _build(self, rng, P) -> _Net:
@@ -269,6 +346,8 @@ class PixelCritic:
         if phis is None:
             phis = self.state_encoder.forward(s)
         n = phis.shape[0]
+        if self.row_passes:
+            return self._learn_rows(phis.contiguous(), a.contiguous(), r.contiguous(), phis_next.contiguous())
         a_next = self.actor.actions(phis_next, target=True)
         q_next = self.target_net.forward(self._rows(phis_next, a_next))[-1]
         acts_ = self.eval_net.forward(self._rows(phis, a.contiguous()))
@@ -283,4 +362,21 @@ class PixelCritic:
         self.eval_net.backward(acts_, dq, need_dx=False)
         self.t_replace_counter.add_(1)
         launch_apply([o.job(self.lr, self.t_replace_counter, self.t_replace_iter) for o in self._opt])
+        return self.loss_out
+
+    def _learn_rows(self, phis: torch.Tensor, a: torch.Tensor, r: torch.Tensor, phis_next: torch.Tensor) -> torch.Tensor:
+        n = phis.shape[0]
+        ws = self._rn.workspace(rows16(n))
+        n_tiles = rows16(n) // 16
+        if self._parts is None or self._parts.numel() < n_tiles:
+            self._parts = torch.empty(n_tiles, dtype=torch.float32, device=phis.device)
+        step = _lib.PixelCriticStep(self.a_pad, self.a_dim, n, self._rn.dn.net(True), self._rn_t.dn.net(), self.actor._rn_t.dn.net(),
+                                    mat(phis), mat(phis_next), mat(a), r.data_ptr(), self.gamma, ws.acts(), self._parts.data_ptr(),
+                                    self.t_replace_counter.data_ptr())
+        check(lib.rlgan_pixel_critic_step_rows(C.byref(step), _stream()), "rlgan_pixel_critic_step_rows")
+        launch_wgrads([wgrad_job(self._rn.dn, ws)], 256, self.a_pad)
+        red = reduce_job(self._rn.dn, ws, self._parts, n_tiles, 1.0 / n, self.loss_out)
+        red.grad = self._rn.grad.data_ptr()
+        launch_apply([rmsprop_job(self._rn.dn, self._rn.grad, self._ms, self.lr, target=self._rn_t.dn, counter=self.t_replace_counter,
+                                  period=self.t_replace_iter)], reduces=[red])
         return self.loss_out

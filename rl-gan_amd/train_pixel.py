@@ -134,6 +134,10 @@ class PixelAgent:
                 L.pack()
         for L in self.generator.decoder.layers:
             L.pack()
+        for net in (self.actor, self.critic):                     # the row-pass kernels read fragment images as well
+            if getattr(net, "row_passes", False):
+                net._rn.repack()
+                net._rn_t.repack()
 
     def learn_minibatch(self) -> dict:
         """Curious_GAN_mario.py:82-103 on one sampled minibatch; returns the three evaluated losses."""

@@ -109,9 +109,11 @@ def test_actor_step(n, ad):
     a, da, G = od.actor_policy_grads(phis, A, C)
     ev = actor.eval_net.layers
     before = [L.canon.cpu().numpy().copy() for L in ev]
+    a_dev = actor.actions(_dev(phis)).clone()                        # the action the step is about to differentiate
     actor.learn(None, critic, phis=_dev(phis))
-    close(actor._acts[-1].cpu().numpy()[:, :ad], a, what="a")
-    assert not actor._acts[-1][:, ad:].any()
+    assert actor.row_passes == (ad <= 12)                            # (37, 14): 16 action columns, the layer-by-layer form
+    close(a_dev.cpu().numpy()[:, :ad], a, what="a")
+    assert not a_dev[:, ad:].any()
     got_g = _layer_grads(actor.eval_net, [("w1", "b1"), ("w2", "b2"), ("w3", "b3"), ("wa", "ba")], [(H, 200), (200, 200), (200, 10), (10, ad)])
     for k in G:
         close(got_g[k], G[k].reshape(got_g[k].shape), what="d" + k)
@@ -132,6 +134,62 @@ def test_actor_step(n, ad):
     for Lt, Le in zip(actor.target_net.layers, ev):
         assert torch.equal(Lt.canon, Le.canon)
     assert torch.equal(actor.LSTM_unit_.cell.canon, actor.LSTM_unit.cell.canon)
+
+
+@pytest.mark.parametrize("n", [16, 100, 4096])
+def test_row_passes_against_the_layer_by_layer_form(n):
+    """The two forms of the steps -- one row-pass launch over 16-row tiles, or a matrix product per layer -- from the
+    same parameters on the same minibatch (full tiles, a ragged last tile, the bench's batch): loss, every gradient, the
+    updated parameters, optimizer slots and target copies agree to float32 rounding; three steps in a row."""
+    from gpu_util import close
+    from oracle import pixel_ddpg as od
+    ad = 6
+    rng = np.random.RandomState(9)
+    phis64, phis_n64 = _f32(rng.uniform(0, 2, (n, H))), _f32(rng.uniform(0, 2, (n, H)))
+    a64, r64 = np.eye(ad)[rng.randint(0, ad, n)], _f32(rng.uniform(0, 1, (n, 1)))
+    phis, phis_n, a, r = _dev(phis64), _dev(phis_n64), _dev(a64), _dev(r64)
+    pairs = []
+    for rows in (True, False):
+        actor, critic, A, Cp, At, Ct, _ = _setup(ad, seed=5)
+        assert actor.row_passes and critic.row_passes
+        actor.row_passes = critic.row_passes = rows
+        pairs.append((actor, critic))
+    loss64, G64 = od.critic_loss_and_grads(phis64, a64, r64, phis_n64, Cp, Ct, At, 0.99)
+    for it in range(3):
+        losses = [float(c.learn(None, a, r, None, phis=phis, phis_next=phis_n).item()) for _, c in pairs]
+        assert abs(losses[0] - losses[1]) <= 1e-5 * abs(losses[1])
+        if it == 0:                                                  # the row passes against the float64 restatement, the usual bar
+            assert abs(losses[0] - loss64) <= 1e-5 * loss64
+            c = pairs[0][1]
+            g1 = c.eval_net.layers[0].grad.cpu().numpy()
+            W = g1[:c.k_pad * 200].reshape(c.k_pad, 200)
+            close(W[:H], G64["w1_s"], what="dw1_s"); close(W[H:H + ad], G64["w1_a"], what="dw1_a"); close(g1[c.k_pad * 200:], G64["b1"], what="db1")
+            got = _layer_grads(c.eval_net, [("w1", "b1"), ("w2", "b2"), ("w3", "b3"), ("wq", "bq")], [(c.k_pad, 200), (200, 200), (200, 10), (10, 1)])
+            for k in ("w2", "b2", "w3", "b3", "wq", "bq"):
+                close(got[k], G64[k].reshape(got[k].shape), what="critic d" + k)
+        for act, c in pairs:
+            act.learn(None, c, phis=phis)
+        for (a0, c0), (a1, c1) in [pairs]:
+            for net0, net1, what in ((c0, c1, "critic"), (a0, a1, "actor")):
+                for i, (L0, L1) in enumerate(zip(net0.eval_net.layers, net1.eval_net.layers)):
+                    # Two float32 evaluations: a few 1e-7 apart in every sum, and at 4096 rows some hidden unit of some row
+                    # has its pre-activation within rounding of 0 or 6, where relu6' differs between the two (measured
+                    # here: 8.6e-5 of the tensor's scale in dW2 of the layer-by-layer form against the float64
+                    # restatement, the row passes within 3e-7).  One such row is 1/4096 of a column's terms.
+                    close(L0.grad.cpu().numpy(), L1.grad.cpu().numpy().astype(np.float64), rtol=5e-5 if n <= 100 else 1e-3,
+                          what=f"{what} layer {i} gradient, step {it}")
+                    # an RMSProp step moves a weight by about lr = 1e-4 whatever its gradient's size: the two forms' steps
+                    # differ by the gradients' relative difference
+                    wtol = (5e-7 if n <= 100 else 2e-6) * (it + 1)
+                    np.testing.assert_allclose(L0.canon.cpu().numpy(), L1.canon.cpu().numpy(), rtol=0, atol=wtol)
+                for o0, o1 in zip(net0._opt, net1._opt):
+                    np.testing.assert_allclose(o0.ms.cpu().numpy(), o1.ms.cpu().numpy(), rtol=1e-5 if n <= 100 else 2e-3, atol=1e-9)
+                for T0, T1 in zip(net0.target_net.layers, net1.target_net.layers):
+                    np.testing.assert_allclose(T0.canon.cpu().numpy(), T1.canon.cpu().numpy(), rtol=0, atol=wtol)
+            assert int(c0.t_replace_counter.item()) == int(c1.t_replace_counter.item()) == it + 1
+    # the layer-by-layer calls read the same parameters the row passes wrote: the layers are views of the flat vector
+    a0, c0 = pairs[0]
+    np.testing.assert_allclose(a0.actions(phis).cpu().numpy(), pairs[1][0].actions(phis).cpu().numpy(), rtol=0, atol=2e-5)
 
 
 def test_steps_from_frames_and_action_choice():

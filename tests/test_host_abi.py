@@ -48,7 +48,9 @@ def test_ctypes_records_have_the_c_sizes(tmp_path):
     recs = {"rlgan_geom_t": _lib.Geom, "rlgan_net_t": _lib.Net, "rlgan_acts_t": _lib.Acts, "rlgan_mat_t": _lib.Mat,
             "rlgan_env_t": _lib.Env, "rlgan_critic_step_t": _lib.CriticStep, "rlgan_actor_step_t": _lib.ActorStep,
             "rlgan_disc_step_t": _lib.DiscStep, "rlgan_gen_step_t": _lib.GenStep, "rlgan_wgrad_job_t": _lib.WgradJob,
-            "rlgan_reduce_job_t": _lib.ReduceJob, "rlgan_apply_job_t": _lib.ApplyJob}
+            "rlgan_reduce_job_t": _lib.ReduceJob, "rlgan_apply_job_t": _lib.ApplyJob,
+            "rlgan_pixel_critic_step_t": _lib.PixelCriticStep, "rlgan_pixel_actor_step_t": _lib.PixelActorStep,
+            "rlgan_deconv_fused_geom_t": _lib.DeconvFusedGeom}
     src = tmp_path / "sz.c"
     body = "".join(f'  printf("{n} %zu\\n", sizeof({n}));\n' for n in recs)
     src.write_text(f'#include <stdio.h>\n#include "rlgan_amd.h"\nint main(void) {{\n{body}  return 0;\n}}\n')
@@ -96,6 +98,28 @@ def test_maps_are_injective_and_in_range(kind):
     n_bias = 200 + 200 + g.n3 + g.n_out                # biases have no place in the transposed image
     assert (~has_b).sum() == n_bias
     assert mb[has_b].max() < g.wb_floats and np.unique(mb[has_b]).size == has_b.sum()
+
+
+@pytest.mark.parametrize("kind,a_pad", [(4, 8), (5, 8), (4, 4), (5, 12)])
+def test_pixel_network_kinds(kind, a_pad):
+    """Actor (4) and critic (5) of the pixel variant (Conv_model.py:621-651,711-744) on 256 features: parameter counts of
+    the four layer-wise blocks, a first layer of 17 k-groups, maps that take every parameter once."""
+    g, mf, mb, mg = _maps(kind, 256, a_pad)
+    k0 = 256 + (a_pad if kind == 5 else 0)
+    n_out = a_pad if kind == 4 else 4
+    assert (g.k0, g.n3, g.n_out, g.ld3) == (k0, 12, n_out, 16)
+    assert g.n_params == (k0 + 1) * 200 + 201 * 200 + 201 * 12 + 13 * n_out
+    assert mf.min() >= 0 and mf.max() < g.wf_floats and np.unique(mf).size == g.n_params
+    assert mg.min() >= 0 and mg.max() < g.gpad_floats and np.unique(mg).size == g.n_params
+    has_b = mb >= 0
+    assert (~has_b).sum() == 200 + 200 + 12 + n_out and np.unique(mb[has_b]).size == has_b.sum() and mb[has_b].max() < g.wb_floats
+    # the first layer's bias row follows the last input row: k-group 16 of 17, 13 column tiles
+    assert mf[k0 * 200] == ((k0 // 16 * 13 + 0) * 64 + 16 * ((k0 % 16) // 4) + 0) * 4 + k0 % 4
+    gg = _lib.Geom()
+    assert _lib.lib.rlgan_geometry(kind, 128, a_pad, C.byref(gg)) == -2        # 256 features only
+    assert _lib.lib.rlgan_geometry(kind, 256, 16, C.byref(gg)) == -2           # 4 .. 12 action columns
+    assert _lib.lib.rlgan_geometry(kind, 256, 6, C.byref(gg)) == -2            # a multiple of 4
+    assert _lib.lib.rlgan_pixel_critic_step_rows(None, None) == -1 and _lib.lib.rlgan_pixel_actor_step_rows(None, None) == -1
 
 
 def test_forward_fragment_layout_is_the_documented_one():
