@@ -187,26 +187,28 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvG g, const S sr
   }
 }
 
-// Forward pass of a first layer with four input channels and at most 47 patch elements (3x3 kernels) whose image
-// fits LDS: a workgroup stages one image with coalesced loads and gathers the patch quads from there (a quad is one
-// input pixel's four channels: one ds_read_b128 per k-group), the layer's six weight fragments stay in registers.
-// conv_fwd_kernel fetches every quad from memory, lanes 32 bytes apart, each input pixel about k*k/s*s times.
-template <int NT, class S>
+// Forward pass of a first layer with four input channels: a workgroup stages a band of input rows of one image in
+// LDS with coalesced loads (the rows that `band_h` output rows need; a small image is one band) and gathers the patch
+// quads from there (a quad is one input pixel's four channels: one ds_read_b128 per k-group); the layer's weight
+// fragments (at most MAXG k-groups) stay in registers.  conv_fwd_kernel fetches every quad from memory, lanes 16 * stride
+// bytes apart, each input pixel about k*k / (s*s) times.  grid = (images, bands).
+template <int NT, int MAXG, class S>
 __global__ __launch_bounds__(256) void conv_fwd_c4_kernel(const ConvG g, const S src, const float* __restrict__ wfrag,
-                                                          float* __restrict__ y, int act_elu) {
-  extern __shared__ __attribute__((aligned(16))) float X[];      // [H * W][4]
-  constexpr int MAXG = 3, STAGE_U = 4;
+                                                          float* __restrict__ y, int band_h, int act_elu) {
+  extern __shared__ __attribute__((aligned(16))) float X[];      // [band rows * W][4]
+  constexpr int STAGE_U = 4;
   const int lane = threadIdx.x & 63, wave = wave_id(), q = lane >> 4, j = lane & 15;
-  const int n = blockIdx.x, HW = g.H * g.W, npix = g.Ho * g.Wo;
+  const int n = blockIdx.x, oy0 = blockIdx.y * band_h, oh = min(band_h, g.Ho - oy0);
+  const int in0 = (g.s * oy0) * g.W, nin = ((oh - 1) * g.s + g.k) * g.W, npix = oh * g.Wo;   // input pixels staged, output pixels made
   const long long base = src.image(n);
-  for (int i0 = threadIdx.x; i0 < HW; i0 += 256 * STAGE_U) {
+  for (int i0 = threadIdx.x; i0 < nin; i0 += 256 * STAGE_U) {
     typename S::Raw raw[STAGE_U];
 #pragma unroll
-    for (int u = 0; u < STAGE_U; ++u) raw[u] = src.load(base, (size_t)4 * min(i0 + 256 * u, HW - 1));
+    for (int u = 0; u < STAGE_U; ++u) raw[u] = src.load(base, (size_t)4 * (in0 + min(i0 + 256 * u, nin - 1)));
 #pragma unroll
     for (int u = 0; u < STAGE_U; ++u) {
       const int i = i0 + 256 * u;
-      if (i < HW) *(f32x4*)(X + 4 * i) = src.value(raw[u], base);
+      if (i < nin) *(f32x4*)(X + 4 * i) = src.value(raw[u], base);
     }
   }
   f32x4 w[MAXG][NT];
@@ -224,7 +226,7 @@ __global__ __launch_bounds__(256) void conv_fwd_c4_kernel(const ConvG g, const S
     one[gi] = k0 == g.K ? 1.f : 0.f;
   }
   __syncthreads();
-  float* yn = y + (size_t)n * npix * g.Cout;
+  float* yn = y + ((size_t)n * g.Ho * g.Wo + (size_t)oy0 * g.Wo) * g.Cout;
   for (int t = wave; t < (npix + 15) / 16; t += 4) {
     const int p = min(16 * t + j, npix - 1), oy = fdiv(p, g.dWo), ox = p - oy * g.Wo;
     const float* xp = X + ((g.s * oy) * g.W + g.s * ox) * 4;
@@ -1099,13 +1101,24 @@ int launch_fwd(const ConvG& g, const S& src, const float* wfrag, float* y, int n
   const long long Ml = (long long)n_images * g.Ho * g.Wo;
   if (Ml > 0x7fffffffll || ((uintptr_t)y & 15)) return RLGAN_E_ALIGN;
   const int M = (int)Ml;
-  if (g.Cin == 4 && g.NG <= 3 && g.NT <= 2 && (size_t)g.H * g.W * 16 <= 48 * 1024 && !((uintptr_t)wfrag & 15)) {
-    // a small first layer: one image per workgroup, staged in LDS
-    const size_t ilds = (size_t)g.H * g.W * 16;
-    hipStream_t st = (hipStream_t)stream;
-    if (g.NT == 1) hipLaunchKernelGGL((conv_fwd_c4_kernel<1, S>), dim3(n_images), dim3(256), ilds, st, g, src, wfrag, y, act_elu);
-    else hipLaunchKernelGGL((conv_fwd_c4_kernel<2, S>), dim3(n_images), dim3(256), ilds, st, g, src, wfrag, y, act_elu);
-    return launched();
+  if (g.Cin == 4 && g.NG <= 3 && g.NT <= 2 && !((uintptr_t)wfrag & 15)) {      // 3x3 kernels; the 5x5 stride-4 layer measured no faster this way (128 against 122 us)
+    // a first layer: one band of one image per workgroup, staged in LDS.  The band: as many output rows as 48 KB of
+    // input rows allow (a 42x42 frame is one band, an 84x84 frame three or four); a clamped staging address must stay
+    // inside the band's rows, and a gathered quad inside the staged rows, which the row count below guarantees.
+    const int row_bytes = g.W * 16;
+    const int max_rows = (48 * 1024) / row_bytes;
+    int band_h = max_rows >= g.k ? (max_rows - g.k) / g.s + 1 : 0;
+    if (band_h >= 1) {
+      band_h = std::min(band_h, g.Ho);
+      const int bands = cdiv(g.Ho, band_h);
+      band_h = cdiv(g.Ho, bands);                             // even bands
+      const size_t ilds = (size_t)((band_h - 1) * g.s + g.k) * row_bytes;
+      const dim3 grid(n_images, cdiv(g.Ho, band_h));
+      hipStream_t st = (hipStream_t)stream;
+      if (g.NT == 1) hipLaunchKernelGGL((conv_fwd_c4_kernel<1, 3, S>), grid, dim3(256), ilds, st, g, src, wfrag, y, band_h, act_elu);
+      else hipLaunchKernelGGL((conv_fwd_c4_kernel<2, 3, S>), grid, dim3(256), ilds, st, g, src, wfrag, y, band_h, act_elu);
+      return launched();
+    }
   }
   // workgroups per compute unit: as many as the LDS copies of the weights allow (eight at most: one wave per SIMD each)
   const size_t lds = (size_t)g.NG * g.NT * 1024 + (size_t)g.NG * 16;

@@ -353,8 +353,10 @@ class PixelGanTrainer:
             self.a_pred.learn(s, s_next, a)
         if self.critic is not None:
             r = rows[:, self.D.a_dim + 1:self.D.a_dim + 2].contiguous()
-            phis_next = self.critic.state_encoder.forward(s_next)
-            phis = self.critic.state_encoder.forward(s)
+            # the encoder has been trained by the two steps above: its features again, read from the uint8 ring in place
+            # (bit-equal to encoding the gathered float32 frames)
+            phis_next = self.critic.state_encoder.forward(F.ref(self.idx, "s_"))
+            phis = self.critic.state_encoder.forward(ref)
             self.critic.learn(None, a, r, None, phis=phis, phis_next=phis_next)
             self.actor.learn(None, self.critic, phis=phis)
 
