@@ -306,6 +306,11 @@ int rlgan_frames_store(uint8_t* ring, int64_t slots, int32_t frame_bytes, const 
                        const int64_t* slot_idx, void* stream);
 int rlgan_frames_gather(const uint8_t* ring, int64_t slots, int32_t frame_bytes, const int64_t* idx, int32_t n, float scale,
                         float* out, void* stream);
+/* One channel of the gathered frames, the `b_s_[:, :, :, [-1]]` the pixel loop hands to the discriminator
+ * (Curious_GAN_mario.py:92): out[i, p] = float(ring[idx[i], p * channels + channel]) * scale, out float32
+ * [n][pixels], frames of pixels * channels bytes; the same values as that slice of rlgan_frames_gather's output. */
+int rlgan_frames_gather_channel(const uint8_t* ring, int64_t slots, int32_t pixels, int32_t channels, int32_t channel,
+                                const int64_t* idx, int32_t n, float scale, float* out, void* stream);
 
 /* ---- fused acting path for n_env environments (Curious_GAN.py:190-198,222-234) -------------------
  * a = clip(actor(s) + var*z, -1, 1); g = G(s, a); (s', r, done) = env.step(a);

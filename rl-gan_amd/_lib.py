@@ -221,6 +221,7 @@ PROTOTYPES = {
     "rlgan_conv_backward_weights_u8": [C.POINTER(Conv), _vp, C.c_int64, _vp, _f, _vp, _vp, _vp, _i, _vp, _i, _vp],
     "rlgan_frames_store": [_vp, C.c_int64, _i, _vp, _i, _vp, _vp],
     "rlgan_frames_gather": [_vp, C.c_int64, _i, _vp, _i, _f, _vp, _vp],
+    "rlgan_frames_gather_channel": [_vp, C.c_int64, _i, _i, _i, _vp, _i, _f, _vp, _vp],
     "rlgan_dense_slabs": [_i, _i, _i],
     "rlgan_dense_forward": [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp],
     "rlgan_dense_backward_input": [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp],

@@ -119,8 +119,9 @@ class ConvLayer:
                                                  ns, self.grad.data_ptr(), frames.n, _stream()),
               "rlgan_conv_backward_weights_u8")
 
-    def backward(self, x: torch.Tensor, y: torch.Tensor, dy: torch.Tensor, need_dx: bool = True, act: bool = True):
-        """Gradients of this layer: fills self.grad (kernel then bias), returns dx or None."""
+    def backward(self, x: torch.Tensor, y: torch.Tensor, dy: torch.Tensor, need_dx: bool = True, act: bool = True,
+                 need_dw: bool = True):
+        """Gradients of this layer: fills self.grad (kernel then bias) unless need_dw is False, returns dx or None."""
         n = x.shape[0]
         use_mfma = self.wdx is not None and not self.gather_dx
         # ELU' is applied by the consumers as they read dy (no pass of its own) unless the gather kernel runs
@@ -129,9 +130,10 @@ class ConvLayer:
         if act and not fuse:
             dz = torch.empty_like(dy)
             check(lib.rlgan_elu_backward(dy.data_ptr(), y.data_ptr(), dz.data_ptr(), dy.numel(), _stream()), "rlgan_elu_backward")
-        slabs, ns = self._slab_buffer(n)
-        check(lib.rlgan_conv_backward_weights(self.conv, x.data_ptr(), dz.data_ptr(), yel, slabs.data_ptr(), ns,
-                                              self.grad.data_ptr(), n, _stream()), "rlgan_conv_backward_weights")
+        if need_dw:
+            slabs, ns = self._slab_buffer(n)
+            check(lib.rlgan_conv_backward_weights(self.conv, x.data_ptr(), dz.data_ptr(), yel, slabs.data_ptr(), ns,
+                                                  self.grad.data_ptr(), n, _stream()), "rlgan_conv_backward_weights")
         if not need_dx:
             return None
         dx = torch.empty_like(x)
@@ -189,8 +191,8 @@ class DenseLayer:
                                       self._act_code(act), None if sc is None else sc.data_ptr(), ns, _stream()), "rlgan_dense_forward")
         return y
 
-    def backward(self, x: torch.Tensor, y: torch.Tensor, dy: torch.Tensor, need_dx: bool = True, act=True):
-        """Gradients of this layer: fills self.grad (kernel then bias), returns dx or None."""
+    def backward(self, x: torch.Tensor, y: torch.Tensor, dy: torch.Tensor, need_dx: bool = True, act=True, need_dw: bool = True):
+        """Gradients of this layer: fills self.grad (kernel then bias) unless need_dw is False, returns dx or None."""
         m = x.shape[0]
         dz = dy
         code = self._act_code(act)
@@ -201,9 +203,10 @@ class DenseLayer:
             else:
                 fn, name = (lib.rlgan_elu_backward, "rlgan_elu_backward") if code == 1 else (lib.rlgan_relu_backward, "rlgan_relu_backward")
                 check(fn(dy.data_ptr(), y.data_ptr(), dz.data_ptr(), dy.numel(), _stream()), name)
-        sc, ns = self._slabs(self.k + 1, m)
-        check(lib.rlgan_dense_backward_weights(x.data_ptr(), self.k, dz.data_ptr(), self.n, self.grad.data_ptr(), m, self.k, self.n,
-                                               None if sc is None else sc.data_ptr(), ns, _stream()), "rlgan_dense_backward_weights")
+        if need_dw:
+            sc, ns = self._slabs(self.k + 1, m)
+            check(lib.rlgan_dense_backward_weights(x.data_ptr(), self.k, dz.data_ptr(), self.n, self.grad.data_ptr(), m, self.k, self.n,
+                                                   None if sc is None else sc.data_ptr(), ns, _stream()), "rlgan_dense_backward_weights")
         if not need_dx:
             return None
         dx = torch.empty_like(x)
@@ -249,14 +252,17 @@ class ConvEncoder:
         self._flat, self._out = flat, self.head.forward(flat)
         return self._out
 
-    def backward(self, dfeat: torch.Tensor, need_dx: bool = False) -> Optional[torch.Tensor]:
-        """Backpropagates d(loss)/d(features) through the stack; every layer's .grad is filled."""
+    def backward(self, dfeat: torch.Tensor, need_dx: bool = False, need_dw: bool = True) -> Optional[torch.Tensor]:
+        """Backpropagates d(loss)/d(features) through the stack; every layer's .grad is filled, or with need_dw False
+        left as it is (a loss that only passes through the encoder, like the generator's: Conv_model.py:529-531)."""
+        assert need_dw or need_dx
         if self.head is not None:
-            dfeat = self.head.backward(self._flat, self._out, dfeat.contiguous())
+            dfeat = self.head.backward(self._flat, self._out, dfeat.contiguous(), need_dw=need_dw)
         dy = dfeat.reshape(self._acts[-1].shape).contiguous()
         for i in range(len(self.layers) - 1, -1, -1):
             if i == 0 and isinstance(self._acts[0], FrameRef):
-                self.layers[0].backward_frames(self._acts[0], self._acts[1], dy)
+                if need_dw:
+                    self.layers[0].backward_frames(self._acts[0], self._acts[1], dy)
                 return None
-            dy = self.layers[i].backward(self._acts[i], self._acts[i + 1], dy, need_dx=need_dx or i > 0)
+            dy = self.layers[i].backward(self._acts[i], self._acts[i + 1], dy, need_dx=need_dx or i > 0, need_dw=need_dw)
         return dy

@@ -115,6 +115,18 @@ __global__ __launch_bounds__(256) void frames_gather_kernel(const uint32_t* __re
   }
 }
 
+// one channel of every pixel: out[i][p] = float(ring[idx[i]][p * channels + channel]) * scale
+__global__ __launch_bounds__(256) void frames_gather_channel_kernel(const uint8_t* __restrict__ ring, long long slots, int pixels,
+                                                                    int channels, int channel, const int64_t* __restrict__ idx,
+                                                                    float scale, float* __restrict__ out) {
+  const long long slot = idx[blockIdx.y];
+  const bool ok = slot >= 0 && slot < slots;
+  const uint8_t* src = ring + (size_t)(ok ? slot : 0) * pixels * channels + channel;
+  float* dst = out + (size_t)blockIdx.y * pixels;
+  for (int p = blockIdx.x * 256 + threadIdx.x; p < pixels; p += gridDim.x * 256)
+    dst[p] = ok ? (float)src[(size_t)p * channels] * scale : 0.f;
+}
+
 }  // namespace
 
 extern "C" {
@@ -187,6 +199,15 @@ int rlgan_frames_gather(const uint8_t* ring, int64_t slots, int32_t frame_bytes,
   const int words = frame_bytes / 4;
   hipLaunchKernelGGL(frames_gather_kernel, dim3(std::min(cdiv(words, 1024), 64), n), dim3(256), 0, (hipStream_t)stream,
                      (const uint32_t*)ring, (long long)slots, words, idx, scale, (f32x4*)out);
+  return launched();
+}
+
+int rlgan_frames_gather_channel(const uint8_t* ring, int64_t slots, int32_t pixels, int32_t channels, int32_t channel,
+                                const int64_t* idx, int32_t n, float scale, float* out, void* stream) {
+  if (!ring || !idx || !out || slots <= 0 || pixels <= 0 || n <= 0 || n > 65535) return RLGAN_E_ARG;
+  if (channels <= 0 || channel < 0 || channel >= channels) return RLGAN_E_DIMS;
+  hipLaunchKernelGGL(frames_gather_channel_kernel, dim3(std::min(cdiv(pixels, 256), 64), n), dim3(256), 0, (hipStream_t)stream,
+                     ring, (long long)slots, pixels, channels, channel, idx, scale, out);
   return launched();
 }
 

@@ -21,7 +21,7 @@ import numpy as np
 import torch
 
 from ._lib import check, lib
-from .conv import ConvEncoder, DenseLayer
+from .conv import ConvEncoder, DenseLayer, FrameRef
 from .core import _stream, device, row_ld
 from .pixel_gan import _adam_for, _adam_jobs
 
@@ -109,10 +109,17 @@ class StateActionPredictor:
         self._rows: Optional[torch.Tensor] = None
 
     # ---- pieces ------------------------------------------------------------------------------------
-    def _features(self, s: torch.Tensor, s_next: torch.Tensor) -> torch.Tensor:
-        """[n, 2h] rows [phis, phis'] from one encoder pass over the 2n frames."""
-        n = s.shape[0]
-        f = self.state_encoder.forward(torch.cat([s, s_next], 0).contiguous())
+    def _features(self, s, s_next: Optional[torch.Tensor]) -> torch.Tensor:
+        """[n, 2h] rows [phis, phis'] from one encoder pass over the 2n frames.  s: float32 frames [n, h, w, c] with
+        s_next alike, or a FrameRef naming the 2n frames in the uint8 replay, s first (`FrameMemory.ref_pair`), with
+        s_next None."""
+        if isinstance(s, FrameRef):
+            assert s_next is None and s.n % 2 == 0
+            n = s.n // 2
+            f = self.state_encoder.forward(s)
+        else:
+            n = s.shape[0]
+            f = self.state_encoder.forward(torch.cat([s, s_next], 0).contiguous())
         x = torch.empty((n, 2 * self.h_dim), dtype=torch.float32, device=f.device)
         for c in range(2):
             check(lib.rlgan_copy_cols(f.data_ptr() + 4 * c * n * self.h_dim, self.h_dim, x.data_ptr() + 4 * c * self.h_dim, 2 * self.h_dim,
@@ -149,9 +156,10 @@ class StateActionPredictor:
         return float(self.loss_out.item())
 
     def learn(self, b_s: torch.Tensor, b_s_: torch.Tensor, b_a: torch.Tensor, lr: Optional[float] = None) -> torch.Tensor:
-        """One Adam step (Conv_model.py:864-867); returns the loss before the step (device scalar)."""
-        n = b_s.shape[0]
+        """One Adam step (Conv_model.py:864-867); returns the loss before the step (device scalar).  b_s may be a
+        FrameRef over both frame fields (see `_features`), b_s_ then None."""
         x = self._features(b_s, b_s_)
+        n = x.shape[0]
         z1, h1, z2, h2, z3, out = self._net(x, True)
         dout = self._loss(out, b_a.contiguous(), True)
         dz3 = self.bn3.backward(dout, out, z3, False)

@@ -139,11 +139,11 @@ class PixelGenerator:
 
     def learn(self, phis: torch.Tensor, a: torch.Tensor, single_s_next: torch.Tensor, lr: Optional[float] = None) -> torch.Tensor:
         """One Adam step on the generator's variables (Conv_model.py:533-541); returns the loss before the step
-        (device scalar).  The encoder's gradient buffers are scratch here: its variables are not in the var_list."""
+        (device scalar).  The encoder's variables are not in the var_list: only the input gradient is taken through it."""
         obs = self.features(single_s_next).clone()
         fake = self.features(self.predict_batch(phis, a))      # the encoder now holds the activations of the fake pass
         dfake = self._mse(fake, obs, True)
-        dimg4 = self.obs_encoder.backward(dfake, need_dx=True)
+        dimg4 = self.obs_encoder.backward(dfake, need_dx=True, need_dw=False)
         n, h, w, _ = dimg4.shape
         dimg = torch.empty((n, h, w, 1), dtype=torch.float32, device=dimg4.device)
         check(lib.rlgan_copy_cols(dimg4.data_ptr(), 4, dimg.data_ptr(), 1, n * h * w, 1, 0, _stream()), "rlgan_copy_cols")
@@ -327,6 +327,7 @@ class PixelGanTrainer:
         assert (actor is None) == (critic is None)
         assert critic is None or actions.dims >= discriminator.a_dim + 2
         self.idx = torch.zeros(self.batch, dtype=torch.int64, device=device())
+        self._idx2 = torch.zeros(2 * self.batch, dtype=torch.int64, device=device())
         self._graph = None
 
     def sample(self) -> torch.Tensor:
@@ -339,18 +340,15 @@ class PixelGanTrainer:
         phis = D.state_encoder.forward(ref)
         rows = self.actions.gather(self.idx)
         a = rows[:, :self.D.a_dim].contiguous()
-        s_next = F.gather(self.idx, "s_")
-        n, h, w, c = s_next.shape
-        last = torch.empty((n, h, w, 1), dtype=torch.float32, device=s_next.device)
-        check(lib.rlgan_copy_cols(s_next.data_ptr() + 4 * (c - 1), c, last.data_ptr(), 1, n * h * w, 1, 0, _stream()), "rlgan_copy_cols")
+        last = F.gather_channel(self.idx, -1, "s_")             # b_s_[:, :, :, [-1]], Curious_GAN_mario.py:92
         G.learn(phis, a, last)
         img = G.predict_batch(phis, a)
         D.learn(img, last, ref, a, phis=phis)
         if self.a_pred is None and self.critic is None:
             return
-        s = F.gather(self.idx, "s")
         if self.a_pred is not None:
-            self.a_pred.learn(s, s_next, a)
+            # s and s' of the minibatch as one batch of 2n frames read from the uint8 ring in place
+            self.a_pred.learn(F.ref_pair(self.idx, out=self._idx2), None, a)
         if self.critic is not None:
             r = rows[:, self.D.a_dim + 1:self.D.a_dim + 2].contiguous()
             # the encoder has been trained by the two steps above: its features again, read from the uint8 ring in place

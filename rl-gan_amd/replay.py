@@ -153,8 +153,9 @@ class FrameMemory:
         assert self.frame_bytes % 4 == 0, "frame stacks are moved four pixels at a time"
         dev = device()
         self.slots = self.capacity + 1
-        self._s = torch.zeros((self.slots, self.frame_bytes), dtype=torch.uint8, device=dev)
-        self._s_next = torch.zeros((self.slots, self.frame_bytes), dtype=torch.uint8, device=dev)
+        # both fields in one allocation, s' after s: slot i of s' is row slots + i, so one index array can name frames of both
+        self._both = torch.zeros((2 * self.slots, self.frame_bytes), dtype=torch.uint8, device=dev)
+        self._s, self._s_next = self._both[:self.slots], self._both[self.slots:]
         self.pointer = 0
         self.len = 0
         self.rng = rng
@@ -207,6 +208,31 @@ class FrameMemory:
         """The frames of slots idx as a FrameRef: a conv encoder reads them in place, without the float32 copy."""
         from .conv import FrameRef
         return FrameRef(self._s if which == "s" else self._s_next, idx, self.SCALE)
+
+    def ref_pair(self, idx: torch.Tensor, out: Optional[torch.Tensor] = None):
+        """s of slots idx followed by s' of the same slots as ONE FrameRef of 2n frames (the inverse model encodes both,
+        Conv_model.py:864-867).  out: int64 [2n] on the device for the joined index array (rewritten by every call, so a
+        recorded graph that reads it follows the current idx)."""
+        from .conv import FrameRef
+        n = idx.numel()
+        if out is None:
+            out = torch.empty(2 * n, dtype=torch.int64, device=idx.device)
+        out[:n].copy_(idx)
+        torch.add(idx, self.slots, out=out[n:])
+        return FrameRef(self._both, out, self.SCALE)
+
+    def gather_channel(self, idx: torch.Tensor, channel: int = -1, which: str = "s_", out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """float32 [n, h, w, 1]: one channel of the frames of slots idx, `b_s_[:, :, :, [-1]]` of Curious_GAN_mario.py:92
+        by default -- the same values as that slice of `gather`, without the other channels' float32 copies."""
+        ring = self._s if which == "s" else self._s_next
+        c = self.shape[-1]
+        channel = channel % c
+        n, pixels = idx.numel(), self.frame_bytes // c
+        if out is None:
+            out = torch.empty((n,) + self.shape[:-1] + (1,), dtype=torch.float32, device=ring.device)
+        check(lib.rlgan_frames_gather_channel(ring.data_ptr(), self.slots, pixels, c, channel, idx.data_ptr(), n, self.SCALE,
+                                              out.data_ptr(), _stream()), "rlgan_frames_gather_channel")
+        return out
 
     def sample(self, n: int):
         """(indices, b_s, b_s_) on the device: Conv_model.py:145-157 for the two image fields."""

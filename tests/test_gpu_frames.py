@@ -101,6 +101,38 @@ def test_full_size_minibatch_properties():
     assert torch.equal(m._s, before)
 
 
+def test_one_channel_and_both_fields_in_place():
+    """`gather_channel` is the slice of `gather` (Curious_GAN_mario.py:92 takes the newest frame of s'), channels counted
+    from either end, out-of-range slots as zeros; `ref_pair` names s and s' of the same slots as one batch whose encoder
+    features equal those of the gathered float32 frames bit for bit."""
+    import rl_gan_amd as R
+    rs = np.random.RandomState(8)
+    cap, shape, n = 20, (42, 42, 4), 20
+    m = R.FrameMemory(cap, shape, rng=R.MT19937Device(2))
+    m.store_transitions(rs.randint(0, 256, (n,) + shape).astype(np.uint8), rs.randint(0, 256, (n,) + shape).astype(np.uint8))
+    idx = torch.from_numpy(rs.randint(0, n, 33)).cuda()
+    full = {w: m.gather(idx, w) for w in ("s", "s_")}
+    assert torch.equal(m.gather_channel(idx), full["s_"][..., 3:])
+    assert torch.equal(m.gather_channel(idx, 0, "s"), full["s"][..., :1])
+    assert torch.equal(m.gather_channel(idx, -3, "s"), full["s"][..., 1:2])
+    bad = torch.tensor([3, -1, cap + 1, 5], dtype=torch.int64, device="cuda")
+    g = m.gather_channel(bad, 2, "s")
+    assert not g[1].any() and not g[2].any() and torch.equal(g[0], m.gather(bad[:1], "s")[0, ..., 2:3])
+    odd = R.FrameMemory(6, (4, 4, 3))                         # three channels: a pixel is not a word
+    f = rs.randint(0, 256, (6, 4, 4, 3)).astype(np.uint8)
+    odd.store_transitions(f, f)
+    six = torch.arange(6, device="cuda")
+    assert torch.equal(odd.gather_channel(six, 1, "s"), odd.gather(six, "s")[..., 1:2])
+    enc = R.ConvEncoder(42, 42, 4, R.universe_head(2), rng=rs, dense=256, bias_init=0.001)
+    pair = m.ref_pair(idx)
+    assert pair.n == 66 and torch.equal(pair.idx[:33], idx) and torch.equal(pair.idx[33:], idx + m.slots)
+    want = enc.forward(torch.cat([full["s"], full["s_"]], 0)).clone()
+    assert torch.equal(enc.forward(pair), want)
+    buf = torch.zeros(66, dtype=torch.int64, device="cuda")
+    again = m.ref_pair(idx, out=buf)
+    assert again.idx.data_ptr() == buf.data_ptr() and torch.equal(buf, pair.idx)
+
+
 def test_argument_errors():
     import rl_gan_amd as R
     from rl_gan_amd._lib import lib
@@ -116,6 +148,10 @@ def test_argument_errors():
     assert lib.rlgan_frames_gather(p, 4, 62, i, 4, 1.0, o, None) == E_ALIGN
     assert lib.rlgan_frames_gather(p + 1, 4, 64, i, 4, 1.0, o, None) == E_ALIGN
     assert lib.rlgan_frames_gather(p, 4, 64, i, 4, 1.0, o + 4, None) == E_ALIGN
+    assert lib.rlgan_frames_gather_channel(p, 4, 16, 4, 4, i, 4, 1.0, o, None) == -2          # channel outside the frame's
+    assert lib.rlgan_frames_gather_channel(p, 4, 16, 0, 0, i, 4, 1.0, o, None) == -2
+    assert lib.rlgan_frames_gather_channel(p, 4, 16, 4, 3, None, 4, 1.0, o, None) == E_ARG
+    assert lib.rlgan_frames_gather_channel(p, 4, 16, 4, 3, i, 4, 1.0, o, None) == 0
     assert lib.rlgan_frames_store(p, 4, 64, None, 1, i, None) == E_ARG
     assert lib.rlgan_frames_store(p, 4, 63, p, 1, i, None) == E_ALIGN
     assert lib.rlgan_frames_store(p, 4, 64, p + 2, 1, i, None) == E_ALIGN
