@@ -533,6 +533,13 @@ int rlgan_relu_backward(const float* dy, const float* y, float* dz, int64_t n, v
  * [features, action] rows (Conv_model.py:452), channel padding of the generated 1-channel image to the 4
  * channels the convolution kernels take, and the way back (n_zero = 0). */
 int rlgan_copy_cols(const float* src, int ld_src, float* dst, int ld_dst, int64_t rows, int n_copy, int n_zero, void* stream);
+/* One-channel images [n][h][w] <-> their 2x2 blocks as four channels [n][h/2][w/2][4], channel 2*dy + dx =
+ * image[2Y + dy][2X + dx] (h, w even; both buffers 16-byte aligned).  to_blocks != 0: src is the image.  A 3x3
+ * stride-2 convolution of the image (`universe_feature_abstraction(single_S_, time_step=1)`, Conv_model.py:36-49,
+ * Curious_GAN_mario.py:313-314) is a 2x2 stride-1 convolution of the blocks, whose kernel holds the nine taps and seven
+ * zeros: the form the single-frame encoder's first layer runs in; the other direction carries its input gradient
+ * back to the image. */
+int rlgan_blocks2x2(const float* src, float* dst, int64_t n_images, int h, int w, int to_blocks, void* stream);
 /* tf.reduce_mean(tf.squared_difference(fake, real)) (Conv_model.py:527): parts[b] = sum of (fake-real)^2 over
  * workgroup b's 4096 elements (n_parts = ceil(n / 4096); the loss is rlgan_sum_parts(parts, n_parts, 1, 1/n)),
  * dfake = 2 (fake - real) / n when non-NULL. */

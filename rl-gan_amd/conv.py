@@ -143,6 +143,84 @@ class ConvLayer:
         return dx
 
 
+class SingleFrameConv(ConvLayer):
+    """First layer of an encoder of ONE-channel frames, `tf.layers.conv2d(s, 32, 3, strides=2)` on [n, h, w, 1]
+    (`universe_feature_abstraction(single_S_, time_step=1)`, Conv_model.py:36-49, Curious_GAN_mario.py:313-314), run as a
+    2x2 stride-1 convolution of the frame's 2x2 blocks ([n, h/2, w/2, 4], channel 2*dy + dx = frame[2Y + dy][2X + dx]):
+    output pixel (Y, X) reads frame rows 2Y..2Y+2 and columns 2X..2X+2, which lie in blocks (Y..Y+1, X..X+1).  The block
+    kernel [2, 2, 4, f] holds the nine taps and seven zeros (frame row or column 2Y+3 / 2X+3); those seven stay zero:
+    their gradient entries are cleared after every weight-gradient pass.  Against padding the frame to four channels
+    this is a quarter of the input bytes and one group of 16 patch elements instead of three.
+
+    kernel: the reference's [k, k, 1, f] (k = 3, stride 2, even h and w)."""
+
+    def __init__(self, h: int, w: int, c_out: int, k: int = 3, stride: int = 2, rng: Optional[np.random.RandomState] = None,
+                 bias_init: float = 0.0, kernel: Optional[np.ndarray] = None, bias: Optional[np.ndarray] = None):
+        assert (k, stride) == (3, 2) and h % 2 == 0 and w % 2 == 0, "3x3 stride-2 on frames of even size"
+        if kernel is None:
+            rng = rng or np.random.RandomState()
+            lim = np.sqrt(6.0 / (k * k + k * k * c_out))                         # glorot uniform on the [3, 3, 1, f] kernel
+            kernel = rng.uniform(-lim, lim, (k, k, 1, c_out))
+            bias = np.full(c_out, bias_init)
+        kernel = np.asarray(kernel, np.float64).reshape(3, 3, c_out)
+        blocks, real = np.zeros((2, 2, 4, c_out)), np.zeros((2, 2, 4, c_out), dtype=bool)
+        for ky in range(3):
+            for kx in range(3):
+                blocks[ky // 2, kx // 2, 2 * (ky % 2) + kx % 2] = kernel[ky, kx]
+                real[ky // 2, kx // 2, 2 * (ky % 2) + kx % 2] = True
+        super().__init__(h // 2, w // 2, 4, c_out, 2, 1, kernel=blocks, bias=bias)
+        self.frame_h, self.frame_w = h, w
+        self._real = real
+        self.mask = torch.from_numpy(np.concatenate([real.ravel(), np.ones(c_out, dtype=bool)]).astype(np.float32)).to(device())
+
+    def _blocks(self, t: torch.Tensor, to_blocks: bool) -> torch.Tensor:
+        n = t.shape[0]
+        shape = (n, self.frame_h // 2, self.frame_w // 2, 4) if to_blocks else (n, self.frame_h, self.frame_w, 1)
+        out = torch.empty(shape, dtype=torch.float32, device=t.device)
+        check(lib.rlgan_blocks2x2(t.data_ptr(), out.data_ptr(), n, self.frame_h, self.frame_w, 1 if to_blocks else 0, _stream()),
+              "rlgan_blocks2x2")
+        return out
+
+    def regroup(self, frames: torch.Tensor) -> torch.Tensor:
+        """[n, h, w, 1] frames -> the [n, h/2, w/2, 4] blocks this layer's forward and backward take."""
+        assert frames.is_cuda and frames.dtype == torch.float32 and frames.is_contiguous()
+        assert tuple(frames.shape[1:]) == (self.frame_h, self.frame_w, 1)
+        return self._blocks(frames, True)
+
+    def ungroup(self, dblocks: torch.Tensor) -> torch.Tensor:
+        """The input gradient in block form -> d(frames) [n, h, w, 1]."""
+        return self._blocks(dblocks.contiguous(), False)
+
+    def kernel_bias(self) -> Tuple[np.ndarray, np.ndarray]:
+        """(kernel [3, 3, 1, f], bias) as the reference holds them."""
+        f = self.canon.cpu().numpy()
+        nk = 16 * self.c_out
+        blocks = f[:nk].reshape(2, 2, 4, self.c_out)
+        kern = np.zeros((3, 3, 1, self.c_out), dtype=f.dtype)
+        for ky in range(3):
+            for kx in range(3):
+                kern[ky, kx, 0] = blocks[ky // 2, kx // 2, 2 * (ky % 2) + kx % 2]
+        return kern, f[nk:]
+
+    def frame_kernel_grad(self) -> Tuple[np.ndarray, np.ndarray]:
+        """self.grad in the reference's shapes: (d kernel [3, 3, 1, f], d bias)."""
+        g = self.grad.cpu().numpy()
+        nk = 16 * self.c_out
+        blocks = g[:nk].reshape(2, 2, 4, self.c_out)
+        assert not blocks[~self._real].any()
+        kern = np.zeros((3, 3, 1, self.c_out), dtype=g.dtype)
+        for ky in range(3):
+            for kx in range(3):
+                kern[ky, kx, 0] = blocks[ky // 2, kx // 2, 2 * (ky % 2) + kx % 2]
+        return kern, g[nk:]
+
+    def backward(self, x, y, dy, need_dx: bool = True, act: bool = True, need_dw: bool = True):
+        dx = super().backward(x, y, dy, need_dx=need_dx, act=act, need_dw=need_dw)
+        if need_dw:
+            self.grad.mul_(self.mask)                          # the seven entries outside the 3x3 window take no gradient
+        return dx
+
+
 class DenseLayer:
     """The fully connected head of the encoders, `tf.layers.dense(features, 256, activation=tf.nn.elu)`
     (Conv_model.py:24 `fc`; Conv_model.py:52-56 `dense1` + elu).  Parameters in canonical order: the
@@ -217,7 +295,8 @@ class DenseLayer:
 
 class ConvEncoder:
     """A stack of ConvLayers on [n, h, w, c] frames; output flattened to [n, features] like the
-    reference's `tf.reshape(s, [-1, prod(shape[1:])])` (Conv_model.py:23,51)."""
+    reference's `tf.reshape(s, [-1, prod(shape[1:])])` (Conv_model.py:23,51).  c_in = 1 (the single-frame encoder,
+    Curious_GAN_mario.py:313-314): frames [n, h, w, 1] in, d(frames) [n, h, w, 1] out, a SingleFrameConv in front."""
 
     def __init__(self, h: int, w: int, c_in: int, layers: Sequence[Tuple[int, int, int]] = DOOM_HEAD,
                  rng: Optional[np.random.RandomState] = None, bias_init: float = 0.0, params=None,
@@ -228,7 +307,10 @@ class ConvEncoder:
         rng = rng or np.random.RandomState()
         for i, (f, k, s) in enumerate(layers):
             kw = {} if params is None else {"kernel": params[i][0], "bias": params[i][1]}
-            L = ConvLayer(h, w, c_in, f, k, s, rng=rng, bias_init=bias_init, **kw)
+            if i == 0 and c_in == 1:                            # one-channel frames: the first layer works on 2x2 blocks
+                L = SingleFrameConv(h, w, f, k, s, rng=rng, bias_init=bias_init, **kw)
+            else:
+                L = ConvLayer(h, w, c_in, f, k, s, rng=rng, bias_init=bias_init, **kw)
             self.layers.append(L)
             h, w, c_in = L.h_out, L.w_out, f
         self.conv_features = h * w * c_in
@@ -242,6 +324,8 @@ class ConvEncoder:
 
     def forward(self, x) -> torch.Tensor:
         """x: float32 frames [n, h, w, c], or a FrameRef (uint8 frames read in place by the first layer)."""
+        if isinstance(self.layers[0], SingleFrameConv):
+            x = self.layers[0].regroup(x)
         self._acts = [x]
         for i, L in enumerate(self.layers):
             x = L.forward_frames(x) if i == 0 and isinstance(x, FrameRef) else L.forward(x)
@@ -265,4 +349,6 @@ class ConvEncoder:
                     self.layers[0].backward_frames(self._acts[0], self._acts[1], dy)
                 return None
             dy = self.layers[i].backward(self._acts[i], self._acts[i + 1], dy, need_dx=need_dx or i > 0, need_dw=need_dw)
+        if need_dx and isinstance(self.layers[0], SingleFrameConv):
+            dy = self.layers[0].ungroup(dy)
         return dy

@@ -173,6 +173,29 @@ __global__ void copy_cols_narrow_kernel(const float* __restrict__ src, int ld_sr
   for (int c = 0; c < n_copy + n_zero; ++c) dst[r * ld_dst + c] = c < n_copy ? src[r * ld_src + c] : 0.f;
 }
 
+// 2x2 blocks of a one-channel image as the four channels of a half-size image, and back:
+//   blocks[i][Y][X][2*dy + dx] = image[i][2Y + dy][2X + dx]          image [n][h][w], blocks [n][h/2][w/2][4]
+// one thread per block: two 8-byte accesses on the image side (lanes side by side in both rows), one 16-byte access on
+// the block side
+template <bool TO_BLOCKS>
+__global__ __launch_bounds__(256) void blocks2x2_kernel(const float* __restrict__ src, float* __restrict__ dst, long long n_blocks,
+                                                        int hb, int wb) {
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  const long long b = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (b >= n_blocks) return;
+  const int X = (int)(b % wb);
+  const long long iy = b / wb;                         // image * hb + Y
+  const long long row0 = (iy * 2) * (2 * wb) + 2 * X;  // image[i][2Y][2X]: images are h * w = 2hb * 2wb floats
+  if (TO_BLOCKS) {
+    const f2 a = *(const f2*)(src + row0), c = *(const f2*)(src + row0 + 2 * wb);
+    *(f32x4*)(dst + 4 * b) = f32x4{a[0], a[1], c[0], c[1]};
+  } else {
+    const f32x4 v = *(const f32x4*)(src + 4 * b);
+    *(f2*)(dst + row0) = f2{v[0], v[1]};
+    *(f2*)(dst + row0 + 2 * wb) = f2{v[2], v[3]};
+  }
+}
+
 constexpr int MSE_PER_WG = 4096;
 __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ fake, const float* __restrict__ real, long long n, float inv_n2,
                                                   float* __restrict__ parts, float* __restrict__ dfake) {
@@ -361,6 +384,18 @@ int rlgan_copy_cols(const float* src, int ld_src, float* dst, int ld_dst, int64_
     hipLaunchKernelGGL(copy_cols_kernel, dim3(cdiv(nc, 256), gy), dim3(256), 0, (hipStream_t)stream,
                        src, ld_src, dst, ld_dst, (long long)rows, n_copy, n_zero);
   }
+  return launched();
+}
+
+int rlgan_blocks2x2(const float* src, float* dst, int64_t n_images, int h, int w, int to_blocks, void* stream) {
+  if (!src || !dst || n_images <= 0 || h <= 0 || w <= 0) return RLGAN_E_ARG;
+  if ((h & 1) || (w & 1)) return RLGAN_E_DIMS;
+  if (((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) return RLGAN_E_ALIGN;   // image rows are then 8-byte aligned (w even)
+  const long long nb = (long long)n_images * (h / 2) * (w / 2);
+  if (nb > (long long)INT32_MAX * 256) return RLGAN_E_DIMS;
+  const dim3 grid((unsigned)((nb + 255) / 256));
+  if (to_blocks) hipLaunchKernelGGL(blocks2x2_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, src, dst, nb, h / 2, w / 2);
+  else hipLaunchKernelGGL(blocks2x2_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, src, dst, nb, h / 2, w / 2);
   return launched();
 }
 

@@ -29,21 +29,17 @@ N_L1 = 200                                                      # Conv_model.py:
 
 def single_frame_encoder(hw: int = 42, n_convs: int = 2, rng: Optional[np.random.RandomState] = None, params=None,
                          dense_params=None, bias_init: float = 0.0) -> ConvEncoder:
-    """`universe_feature_abstraction(single_S_, time_step=1, nConvs=2)` (Curious_GAN_mario.py:313-314) on frames
-    padded from 1 to 4 channels.  params: [(kernel [3,3,1,32], bias), (kernel [3,3,32,32], bias), ...]."""
+    """`universe_feature_abstraction(single_S_, time_step=1, nConvs=2)` (Curious_GAN_mario.py:313-314): an encoder of
+    [n, hw, hw, 1] frames.  params: [(kernel [3,3,1,32], bias), (kernel [3,3,32,32], bias), ...]."""
     from .conv import universe_head
     rng = rng or np.random.RandomState()
-    if params is None:
+    if params is None:                                      # tf.layers.conv2d defaults: glorot-uniform kernels, zero biases
         params, c = [], 1
         for f, k, _ in universe_head(n_convs):
             lim = np.sqrt(6.0 / (k * k * c + k * k * f))
             params.append((rng.uniform(-lim, lim, (k, k, c, f)), np.full(f, bias_init)))
             c = f
-    k0, b0 = params[0]
-    padded = np.zeros(k0.shape[:2] + (4, k0.shape[3]), dtype=np.float64)
-    padded[:, :, :1, :] = k0
-    return ConvEncoder(hw, hw, 4, universe_head(n_convs), rng=rng, bias_init=0.001, params=[(padded, b0)] + list(params[1:]),
-                       dense=256, dense_params=dense_params)
+    return ConvEncoder(hw, hw, 1, universe_head(n_convs), rng=rng, bias_init=0.001, params=params, dense=256, dense_params=dense_params)
 
 
 class _Adam:
@@ -109,15 +105,9 @@ class PixelGenerator:
         at = torch.as_tensor(np.asarray(a, dtype=np.float32)[None], device=device())
         return self.predict_batch(self.state_encoder.forward(st), at).cpu().numpy()[0]
 
-    def _pad4(self, img1: torch.Tensor) -> torch.Tensor:
-        n, h, w, _ = img1.shape
-        out = torch.empty((n, h, w, 4), dtype=torch.float32, device=img1.device)
-        check(lib.rlgan_copy_cols(img1.data_ptr(), 1, out.data_ptr(), 4, n * h * w, 1, 3, _stream()), "rlgan_copy_cols")
-        return out
-
     def features(self, frames1: torch.Tensor) -> torch.Tensor:
         """Single-frame encoder on [n, h, w, 1] frames (Curious_GAN_mario.py:313-314,340-343)."""
-        return self.obs_encoder.forward(self._pad4(frames1.contiguous()))
+        return self.obs_encoder.forward(frames1.contiguous())
 
     def _mse(self, fake: torch.Tensor, real: torch.Tensor, want_grad: bool):
         n = fake.numel()
@@ -143,10 +133,7 @@ class PixelGenerator:
         obs = self.features(single_s_next).clone()
         fake = self.features(self.predict_batch(phis, a))      # the encoder now holds the activations of the fake pass
         dfake = self._mse(fake, obs, True)
-        dimg4 = self.obs_encoder.backward(dfake, need_dx=True, need_dw=False)
-        n, h, w, _ = dimg4.shape
-        dimg = torch.empty((n, h, w, 1), dtype=torch.float32, device=dimg4.device)
-        check(lib.rlgan_copy_cols(dimg4.data_ptr(), 4, dimg.data_ptr(), 1, n * h * w, 1, 0, _stream()), "rlgan_copy_cols")
+        dimg = self.obs_encoder.backward(dfake, need_dx=True, need_dw=False)
         dcode = self.decoder.backward(dimg)
         self.l1.backward(self._x, self._h1, dcode.contiguous(), need_dx=False, act="relu")
         self.step.add_(1)
@@ -218,12 +205,6 @@ class PixelDiscriminator:
         trained = [self.l1, self.l3, self.l2] + state_encoder.layers + [state_encoder.head] + obs_encoder.layers + [obs_encoder.head]
         self._opt = [_adam_for(L) for L in trained]
 
-    def _pad4(self, img1: torch.Tensor) -> torch.Tensor:
-        n, h, w, _ = img1.shape
-        out = torch.empty((n, h, w, 4), dtype=torch.float32, device=img1.device)
-        check(lib.rlgan_copy_cols(img1.data_ptr(), 1, out.data_ptr(), 4, n * h * w, 1, 3, _stream()), "rlgan_copy_cols")
-        return out
-
     def _rows(self, phis: torch.Tensor, feats: torch.Tensor, a: torch.Tensor, copies: int) -> torch.Tensor:
         """[copies * n, k_pad] rows [phis, feats, a, 0]; phis and a repeat for every copy, feats is [copies * n, obs_dim]."""
         n = phis.shape[0]
@@ -246,7 +227,7 @@ class PixelDiscriminator:
     def determine_batch(self, s, a: torch.Tensor, g_image: torch.Tensor) -> torch.Tensor:
         """1 - D_fake for a batch, the intrinsic reward (Conv_model.py:296-303): [n, 1]."""
         phis = self.state_encoder.forward(s)
-        fobs = self.obs_encoder.forward(self._pad4(g_image.contiguous()))
+        fobs = self.obs_encoder.forward(g_image.contiguous())
         _, _, logits = self._net(self._rows(phis, fobs, a.contiguous(), 1))
         out = torch.empty((logits.shape[0], 1), dtype=torch.float32, device=logits.device)
         check(lib.rlgan_one_minus_sigmoid(logits.data_ptr(), 4, logits.shape[0], out.data_ptr(), _stream()), "rlgan_one_minus_sigmoid")
@@ -268,7 +249,7 @@ class PixelDiscriminator:
         if phis is None:                                         # else: the state encoder still holds this batch's activations
             phis = self.state_encoder.forward(s)
         frames = torch.cat([single_s_next, g_image], 0).contiguous()          # real rows first, fake rows after
-        feats = self.obs_encoder.forward(self._pad4(frames))
+        feats = self.obs_encoder.forward(frames)
         x = self._rows(phis, feats, a.contiguous(), 2)
         h1, h3, logits = self._net(x)
         return n, x, h1, h3, logits

@@ -166,3 +166,58 @@ def test_weight_gradient_two_ways(h, cin, cout, k, st, n):
         L.grad.zero_()
         L.backward_frames(R.FrameRef(u8, None, n=n), y, dy)
         assert torch.equal(L.grad, got[ns])
+
+
+@pytest.mark.parametrize("hw,n", [(42, 7), (12, 3)])
+def test_single_frame_first_layer_on_2x2_blocks(hw, n):
+    """One-channel frames (the single-frame encoder, Curious_GAN_mario.py:313-314): the 3x3 stride-2 first layer runs as a
+    2x2 stride-1 convolution of the frame's 2x2 blocks.  Block regrouping and its inverse, features, the frames' gradient
+    and every kernel / bias gradient in the reference's shapes against the float64 restatement on the plain frames; the
+    seven kernel entries outside the 3x3 window get no gradient."""
+    import rl_gan_amd as R
+    from gpu_util import close
+    from oracle import conv as oc
+    rng = np.random.RandomState(hw)
+    f32 = lambda a: a.astype(np.float32).astype(np.float64)
+    spec = oc.universe_head(2)
+    x = f32(rng.uniform(0, 1, (n, hw, hw, 1)))
+    params = [(f32(w), f32(b)) for w, b in oc.init_encoder(rng, spec, 1, bias=0.01)]
+    y, caches = oc.encoder_forward(x, params, spec)
+    dy = f32(rng.standard_normal(y.shape))
+    dx, grads = oc.encoder_backward(dy, params, spec, caches)
+    enc = R.ConvEncoder(hw, hw, 1, spec, params=params)
+    first = enc.layers[0]
+    assert isinstance(first, R.conv.SingleFrameConv) and (first.k, first.stride, first.c_in) == (2, 1, 4)
+    xt = torch.from_numpy(x.astype(np.float32)).cuda()
+    blocks = first.regroup(xt)
+    want = x.reshape(n, hw // 2, 2, hw // 2, 2).transpose(0, 1, 3, 2, 4).reshape(n, hw // 2, hw // 2, 4)
+    np.testing.assert_array_equal(blocks.cpu().numpy(), want.astype(np.float32))
+    assert torch.equal(first.ungroup(blocks), xt)
+    kern, bias = first.kernel_bias()
+    np.testing.assert_array_equal(kern, params[0][0].astype(np.float32)); np.testing.assert_array_equal(bias, params[0][1].astype(np.float32))
+    feat = enc.forward(xt)
+    close(feat.cpu().numpy(), y.reshape(n, -1), what="features")
+    dxt = enc.backward(torch.from_numpy(dy.reshape(n, -1).astype(np.float32)).cuda(), need_dx=True)
+    assert dxt.shape == xt.shape
+    close(dxt.cpu().numpy(), dx, what="d frames")
+    dw0, db0 = first.frame_kernel_grad()                    # asserts that the entries outside the window are zero
+    close(dw0, grads[0][0], what="layer 0 dW"); close(db0, grads[0][1], what="layer 0 db")
+    g1 = enc.layers[1].grad.cpu().numpy()
+    close(g1[:grads[1][0].size].reshape(grads[1][0].shape), grads[1][0], what="layer 1 dW")
+    # the input gradient alone leaves the weight gradients as they are
+    keep = [L.grad.clone() for L in enc.layers]
+    enc.forward(xt)
+    again = enc.backward(torch.from_numpy(dy.reshape(n, -1).astype(np.float32)).cuda(), need_dx=True, need_dw=False)
+    assert torch.equal(again, dxt) and all(torch.equal(a, L.grad) for a, L in zip(keep, enc.layers))
+
+
+def test_blocks2x2_argument_errors():
+    from rl_gan_amd._lib import lib
+    a = torch.zeros(4 * 6 * 6 + 8, device="cuda"); b = torch.zeros(4 * 6 * 6 + 8, device="cuda")
+    f = lib.rlgan_blocks2x2
+    assert f(a.data_ptr(), b.data_ptr(), 4, 6, 6, 1, None) == 0
+    assert f(a.data_ptr(), b.data_ptr(), 4, 5, 6, 1, None) == -2          # odd height
+    assert f(a.data_ptr(), b.data_ptr(), 4, 6, 7, 0, None) == -2
+    assert f(a.data_ptr() + 8, b.data_ptr(), 4, 6, 6, 1, None) == -5      # not 16-byte aligned
+    assert f(None, b.data_ptr(), 4, 6, 6, 1, None) == -1 and f(a.data_ptr(), b.data_ptr(), 0, 6, 6, 1, None) == -1
+    torch.cuda.synchronize()

@@ -71,16 +71,17 @@ def test_discriminator_step_matches_restatement(n, a_dim):
     for name, enc in (("state_encoder", D.state_encoder), ("obs_encoder", D.obs_encoder)):
         for i, (L, (dw, db)) in enumerate(zip(enc.layers + [enc.head], g[name])):
             gl = L.grad.cpu().numpy()
-            got = gl[:gl.size - db.size]
-            if name == "obs_encoder" and i == 0:            # the padded channels carry no gradient
-                got = got.reshape(3, 3, 4, 32)
-                assert not got[:, :, 1:].any()
-                got = got[:, :, :1]
+            got, gb = gl[:gl.size - db.size], gl[gl.size - db.size:]
+            if name == "obs_encoder" and i == 0:            # kept as a 2x2 kernel over 2x2 blocks: seven entries stay zero
+                got, gb = L.frame_kernel_grad()
             close(got.reshape(dw.shape), dw, what=f"{name} {i} dW")
-            close(gl[gl.size - db.size:], db, what=f"{name} {i} db")
+            close(gb, db, what=f"{name} {i} db")
     for L, w0 in zip(trained, before):
         want = Adam(w0.size, 1e-4, dtype=np.float32).step(w0, L.grad.cpu().numpy())
         np.testing.assert_allclose(L.canon.cpu().numpy(), want, rtol=0, atol=2e-7)
+    first = D.obs_encoder.layers[0]
+    kern, _ = first.kernel_bias()
+    assert kern.shape == (3, 3, 1, 32) and not first.canon.cpu().numpy()[:16 * 32].reshape(2, 2, 4, 32)[~first._real].any()
     assert int(D.step.item()) == 1
 
 

@@ -38,9 +38,8 @@ def _encoder_vars(enc, prefix, single=False):
     out = {}
     for i, L in enumerate(enc.layers):
         kern, bias = L.kernel_bias()
-        if single and i == 0:                                # frames padded from 1 to 4 channels: the padding stays zero
-            assert not kern[:, :, 1:].any()
-            kern = kern[:, :, :1]
+        if single and i == 0:                                # run as a 2x2 kernel over 2x2 blocks: the seven extra entries stay zero
+            assert kern.shape == (3, 3, 1, 32) and not L.canon.cpu().numpy()[:16 * 32].reshape(2, 2, 4, 32)[~L._real].any()
         out[f"{prefix}.conv{i}.w"], out[f"{prefix}.conv{i}.b"] = kern, bias
     out[prefix + ".dense.w"], out[prefix + ".dense.b"] = enc.head.kernel_bias()
     return out
