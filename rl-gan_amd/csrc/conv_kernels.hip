@@ -988,7 +988,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_c4_kernel(const ConvG g, const
     }
   }
   __syncthreads();
-  float* red = X;                                        // [4 waves][C4W_RT * NT tiles][64 lanes][4]
+  float* red = lds;                                      // [4 waves][C4W_RT * NT tiles][64 lanes][4] over the image and, for small images, the start of dZ (the host checked the size)
   constexpr int TILES = C4W_RT * NT;
 #pragma unroll
   for (int rt = 0; rt < C4W_RT; ++rt) {
@@ -1151,7 +1151,7 @@ int launch_wgrad(const ConvG& g, const S& src, const float* dz, const float* y_e
     constexpr int XU = 7, ZU = 13;                            // per-thread pieces of an image in flight: 42x42 frames, 20x20x32 maps
     const int HW = g.H * g.W, PP = cdiv(g.Ho * g.Wo, 16) * 16;
     const size_t lds = ((size_t)HW * 4 + (size_t)PP * g.Cout) * sizeof(float) + (size_t)PP * sizeof(unsigned short);
-    if (lds <= 79 * 1024 && (size_t)HW * 16 < 65536 && (size_t)4 * C4W_RT * g.NT * 256 <= (size_t)HW * 4 &&   // two workgroups per compute unit; 16-bit offsets; the wave sums fit the image's space
+    if (lds <= 79 * 1024 && (size_t)HW * 16 < 65536 && (size_t)4 * C4W_RT * g.NT * 256 <= (size_t)HW * 4 + (size_t)PP * g.Cout &&   // two workgroups per compute unit; 16-bit offsets; the wave sums fit the space of the image and dZ
         HW <= 256 * XU && g.Ho * g.Wo * (g.Cout / 4) <= 256 * ZU) {
       const int wgs = std::min(n_slabs, std::min(n_images, 512));
       const int per = cdiv(n_images, wgs), used = cdiv(n_images, per);

@@ -133,11 +133,11 @@ def test_input_gradient_two_ways(h, cin, cout, k, st):
 
 
 @pytest.mark.parametrize("h,cin,cout,k,st,n", [(84, 4, 8, 5, 4, 7), (42, 4, 32, 3, 2, 9), (20, 8, 16, 3, 2, 40), (42, 4, 32, 3, 2, 30),
-                                               (21, 4, 16, 3, 2, 11)])
+                                               (21, 4, 16, 3, 2, 11), (21, 4, 32, 2, 1, 30)])
 def test_weight_gradient_two_ways(h, cin, cout, k, st, n):
     """Layers with few patch elements have two weight-gradient kernels (one slab per workgroup, or per wave when
     every slab covers a long run of pixels): both against the float64 restatement, on float32 frames and on the
-    uint8 ring."""
+    uint8 ring.  The last case is the block form of a one-channel first layer (2x2 taps, stride 1, 21x21 blocks)."""
     import rl_gan_amd as R
     from gpu_util import close
     from oracle import conv as oc
@@ -157,7 +157,7 @@ def test_weight_gradient_two_ways(h, cin, cout, k, st, n):
     # pixels per slab: few (workgroup kernel) / at least 256 (wave kernel); a 3x3 first layer on small frames runs the
     # image-in-LDS kernel either way, one image per workgroup, and with 4 slabs several images per workgroup (the next
     # image is fetched while the current one is multiplied)
-    for ns in (1024, max(4, m // 300)) + ((4,) if cin == 4 and k == 3 else ()):
+    for ns in (1024, max(4, m // 300)) + ((4,) if cin == 4 and k <= 3 else ()):
         L.n_slabs, L._small = ns, False
         L.grad.zero_()
         L.backward(x, y, dy, need_dx=False)
