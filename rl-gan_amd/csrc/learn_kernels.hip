@@ -573,10 +573,14 @@ __global__ __launch_bounds__(256) void apply_kernel(const ApplyArgs A) {
   const float w_old = J.canon[p], s0_old = J.slot0[p];
   const float s1_old = J.opt == 1 ? J.slot1[p] : 0.f;
   const int t_adam = J.opt == 1 ? J.step[0] : 1;
+  const int og = J.gslabs ? J.map_g[p] : 0;
+  const int of = J.wf ? J.map_f[p] : -1;                   // -1: this parameter has no place in the image (or there is no image)
+  const int ob = J.wb ? J.map_b[p] : -1;
+  const bool to_target = J.target_canon && (!J.counter || ((J.counter[0] - 1) % J.period) == 0);
   __builtin_amdgcn_sched_barrier(0);
   float g;
   if (J.gslabs) {
-    const float* src = J.gslabs + J.map_g[p];
+    const float* src = J.gslabs + og;
     float v[MAX_CHUNKS];
 #pragma unroll
     for (int c = 0; c < MAX_CHUNKS; ++c) v[c] = c < J.nchunks ? src[(size_t)c * J.gstride] : 0.f;
@@ -612,10 +616,9 @@ __global__ __launch_bounds__(256) void apply_kernel(const ApplyArgs A) {
     w = w_old - lr_t * m / (sqrtf(v) + J.eps);
   }
   J.canon[p] = w;
-  const int of = J.wf ? J.map_f[p] : -1;                   // -1: this parameter has no place in the image (or there is no image)
   if (of >= 0) J.wf[of] = w;
-  if (J.wb) { const int ob = J.map_b[p]; if (ob >= 0) J.wb[ob] = w; }
-  if (J.target_canon && (!J.counter || ((J.counter[0] - 1) % J.period) == 0)) {
+  if (ob >= 0) J.wb[ob] = w;
+  if (to_target) {
     // hard copy (tau = 1, DDPG.py:99-101,176-178) or Polyak average
     const float tw = J.tau == 1.f ? w : J.tau * w + (1.f - J.tau) * J.target_canon[p];
     J.target_canon[p] = tw;
