@@ -77,7 +77,9 @@ def test_vec_env_matches_reference_logs():
             np.testing.assert_array_equal(env.goal, np.stack([d["goal"][i] for d in logs]))
 
 
-def test_known_answers_from_survey():
+def test_known_answers_of_the_hard_mode_reset_and_first_step():
+    """arm_env.py:43-78,91-115 with np.random.seed(1): the goal the reset draws (truncated to integers) and the state
+    after one step of a = (0.5, -2.0), worked out by hand from the reference's formulas."""
     np.random.seed(1)
     env = ScalarArmEnv("hard")
     s = env.reset()
