@@ -92,10 +92,12 @@ class ConvLayer:
         n = self.k * self.k * self.c_in * self.c_out
         return f[:n].reshape(self.k, self.k, self.c_in, self.c_out), f[n:]
 
-    def forward(self, x: torch.Tensor, act: bool = True) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, act: bool = True, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """out: where the result goes (float32 [n, h_out, w_out, c_out], contiguous), e.g. rows of a larger batch's buffer."""
         n = x.shape[0]
         assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and tuple(x.shape[1:]) == (self.conv.h, self.conv.w, self.c_in)
-        y = torch.empty((n, self.h_out, self.w_out, self.c_out), dtype=torch.float32, device=x.device)
+        y = torch.empty((n, self.h_out, self.w_out, self.c_out), dtype=torch.float32, device=x.device) if out is None else out
+        assert y.is_cuda and y.dtype == torch.float32 and y.is_contiguous() and tuple(y.shape) == (n, self.h_out, self.w_out, self.c_out)
         check(lib.rlgan_conv_forward(self.conv, x.data_ptr(), self.wfrag.data_ptr(), y.data_ptr(), n, 1 if act else 0, _stream()),
               "rlgan_conv_forward")
         return y
@@ -173,19 +175,21 @@ class SingleFrameConv(ConvLayer):
         self._real = real
         self.mask = torch.from_numpy(np.concatenate([real.ravel(), np.ones(c_out, dtype=bool)]).astype(np.float32)).to(device())
 
-    def _blocks(self, t: torch.Tensor, to_blocks: bool) -> torch.Tensor:
+    def _blocks(self, t: torch.Tensor, to_blocks: bool, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         n = t.shape[0]
         shape = (n, self.frame_h // 2, self.frame_w // 2, 4) if to_blocks else (n, self.frame_h, self.frame_w, 1)
-        out = torch.empty(shape, dtype=torch.float32, device=t.device)
+        if out is None:
+            out = torch.empty(shape, dtype=torch.float32, device=t.device)
+        assert out.is_cuda and out.dtype == torch.float32 and out.is_contiguous() and tuple(out.shape) == shape
         check(lib.rlgan_blocks2x2(t.data_ptr(), out.data_ptr(), n, self.frame_h, self.frame_w, 1 if to_blocks else 0, _stream()),
               "rlgan_blocks2x2")
         return out
 
-    def regroup(self, frames: torch.Tensor) -> torch.Tensor:
+    def regroup(self, frames: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """[n, h, w, 1] frames -> the [n, h/2, w/2, 4] blocks this layer's forward and backward take."""
         assert frames.is_cuda and frames.dtype == torch.float32 and frames.is_contiguous()
         assert tuple(frames.shape[1:]) == (self.frame_h, self.frame_w, 1)
-        return self._blocks(frames, True)
+        return self._blocks(frames, True, out)
 
     def ungroup(self, dblocks: torch.Tensor) -> torch.Tensor:
         """The input gradient in block form -> d(frames) [n, h, w, 1]."""
@@ -261,9 +265,10 @@ class DenseLayer:
         the pixel actor and critic; False / None: linear."""
         return {True: 1, "elu": 1, "relu": 2, "relu6": 3, "tanh": 4, False: 0, None: 0}[act]
 
-    def forward(self, x: torch.Tensor, act=True) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, act=True, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.ndim == 2 and x.shape[1] == self.k
-        y = torch.empty((x.shape[0], self.n), dtype=torch.float32, device=x.device)
+        y = torch.empty((x.shape[0], self.n), dtype=torch.float32, device=x.device) if out is None else out
+        assert y.is_cuda and y.dtype == torch.float32 and y.is_contiguous() and tuple(y.shape) == (x.shape[0], self.n)
         sc, ns = self._slabs(x.shape[0], self.k + 1)
         check(lib.rlgan_dense_forward(x.data_ptr(), self.k, self.canon.data_ptr(), y.data_ptr(), self.n, x.shape[0], self.k, self.n,
                                       self._act_code(act), None if sc is None else sc.data_ptr(), ns, _stream()), "rlgan_dense_forward")
@@ -334,6 +339,49 @@ class ConvEncoder:
         if self.head is None:
             return flat
         self._flat, self._out = flat, self.head.forward(flat)
+        return self._out
+
+    # ---- one batch encoded in several calls ----------------------------------------------------------------
+    def new_activation_set(self, total: int) -> List[torch.Tensor]:
+        """Buffers for the activations of `total` frames: the first layer's input, every layer's output and the head's.
+        `forward_rows` fills row ranges of them in separate calls; `use` then makes them the pass `backward` continues from.
+        For a batch whose parts become available at different times while the encoder's variables stay the same (the
+        discriminator's real and generated frames, Conv_model.py:183-199: the real ones are already encoded for the
+        generator's loss), and it keeps the buffers of a recorded graph in one place."""
+        dev = self.layers[0].canon.device
+        first = self.layers[0]
+        sets = [torch.empty((total, first.conv.h, first.conv.w, first.c_in), dtype=torch.float32, device=dev)]
+        for L in self.layers:
+            sets.append(torch.empty((total, L.h_out, L.w_out, L.c_out), dtype=torch.float32, device=dev))
+        if self.head is not None:
+            sets.append(torch.empty((total, self.head.n), dtype=torch.float32, device=dev))
+        return sets
+
+    def forward_rows(self, x: torch.Tensor, acts: List[torch.Tensor], row0: int) -> torch.Tensor:
+        """Encodes float32 frames x [n, h, w, c] into rows row0 .. row0 + n of the activation set; returns their features
+        (a view of the set's last buffer).  A row's results do not depend on what else is in the batch."""
+        n = x.shape[0]
+        rows = slice(row0, row0 + n)
+        assert 0 <= row0 and row0 + n <= acts[0].shape[0]
+        if isinstance(self.layers[0], SingleFrameConv):
+            self.layers[0].regroup(x, out=acts[0][rows])
+        else:
+            acts[0][rows].copy_(x)
+        for i, L in enumerate(self.layers):
+            L.forward(acts[i][rows], out=acts[i + 1][rows])
+        conv_out = acts[len(self.layers)][rows]
+        if self.head is None:
+            return conv_out.reshape(n, -1)
+        return self.head.forward(conv_out.reshape(n, -1), out=acts[-1][rows])
+
+    def use(self, acts: List[torch.Tensor]) -> torch.Tensor:
+        """Makes a filled activation set the encoder's latest pass (what `backward` differentiates); returns its features."""
+        nl = len(self.layers)
+        self._acts = list(acts[:nl + 1])
+        flat = acts[nl].reshape(acts[nl].shape[0], -1)
+        if self.head is None:
+            return flat
+        self._flat, self._out = flat, acts[-1]
         return self._out
 
     def backward(self, dfeat: torch.Tensor, need_dx: bool = False, need_dw: bool = True) -> Optional[torch.Tensor]:

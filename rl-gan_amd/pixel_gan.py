@@ -127,10 +127,13 @@ class PixelGenerator:
         self._mse(self.features(self.predict_batch(phis, a)), obs, False)
         return float(self.loss_out.item())
 
-    def learn(self, phis: torch.Tensor, a: torch.Tensor, single_s_next: torch.Tensor, lr: Optional[float] = None) -> torch.Tensor:
+    def learn(self, phis: torch.Tensor, a: torch.Tensor, single_s_next: torch.Tensor, lr: Optional[float] = None,
+              obs: Optional[torch.Tensor] = None) -> torch.Tensor:
         """One Adam step on the generator's variables (Conv_model.py:533-541); returns the loss before the step
-        (device scalar).  The encoder's variables are not in the var_list: only the input gradient is taken through it."""
-        obs = self.features(single_s_next).clone()
+        (device scalar).  The encoder's variables are not in the var_list: only the input gradient is taken through it.
+        obs: the single-frame encoder's features of single_s_next when the caller already holds them."""
+        if obs is None:
+            obs = self.features(single_s_next).clone()
         fake = self.features(self.predict_batch(phis, a))      # the encoder now holds the activations of the fake pass
         dfake = self._mse(fake, obs, True)
         dimg = self.obs_encoder.backward(dfake, need_dx=True, need_dw=False)
@@ -244,12 +247,16 @@ class PixelDiscriminator:
         (Conv_model.py:305-313)."""
         return 0.
 
-    def _forward_pair(self, s, a, single_s_next, g_image, phis=None):
+    def _forward_pair(self, s, a, single_s_next, g_image, phis=None, obs_set=None):
         n = a.shape[0]
         if phis is None:                                         # else: the state encoder still holds this batch's activations
             phis = self.state_encoder.forward(s)
-        frames = torch.cat([single_s_next, g_image], 0).contiguous()          # real rows first, fake rows after
-        feats = self.obs_encoder.forward(frames)
+        if obs_set is not None:                                  # both halves are already encoded: real rows first, fake rows after
+            feats = self.obs_encoder.use(obs_set)
+            assert feats.shape[0] == 2 * n
+        else:
+            frames = torch.cat([single_s_next, g_image], 0).contiguous()
+            feats = self.obs_encoder.forward(frames)
         x = self._rows(phis, feats, a.contiguous(), 2)
         h1, h3, logits = self._net(x)
         return n, x, h1, h3, logits
@@ -261,10 +268,13 @@ class PixelDiscriminator:
         real, fake = self.losses.tolist()
         return real + fake
 
-    def learn(self, g_image, single_s_next, s, a, lr: Optional[float] = None, phis: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def learn(self, g_image, single_s_next, s, a, lr: Optional[float] = None, phis: Optional[torch.Tensor] = None,
+              obs_set=None) -> torch.Tensor:
         """One Adam step (Conv_model.py:270-281); returns (D_loss_real, D_loss_fake) before the step (device).
-        phis: features of `s` from a forward pass of the state encoder that is still its latest one (saves the pass)."""
-        n, x, h1, h3, logits = self._forward_pair(s, a, single_s_next, g_image, phis)
+        phis: features of `s` from a forward pass of the state encoder that is still its latest one (saves the pass).
+        obs_set: an activation set of the single-frame encoder (`ConvEncoder.new_activation_set(2n)`) whose rows 0..n hold
+        the pass over single_s_next and rows n..2n the pass over g_image, both with the encoder's current variables."""
+        n, x, h1, h3, logits = self._forward_pair(s, a, single_s_next, g_image, phis, obs_set)
         dlogits = torch.empty_like(logits)
         check(lib.rlgan_sigmoid_ce(logits.data_ptr(), 4, n, n, self.losses.data_ptr(), dlogits.data_ptr(), _stream()), "rlgan_sigmoid_ce")
         dh3 = self.l2.backward(h3, logits, dlogits, act=False)
@@ -309,6 +319,7 @@ class PixelGanTrainer:
         assert critic is None or actions.dims >= discriminator.a_dim + 2
         self.idx = torch.zeros(self.batch, dtype=torch.int64, device=device())
         self._idx2 = torch.zeros(2 * self.batch, dtype=torch.int64, device=device())
+        self._ob_set = None
         self._graph = None
 
     def sample(self) -> torch.Tensor:
@@ -322,9 +333,20 @@ class PixelGanTrainer:
         rows = self.actions.gather(self.idx)
         a = rows[:, :self.D.a_dim].contiguous()
         last = F.gather_channel(self.idx, -1, "s_")             # b_s_[:, :, :, [-1]], Curious_GAN_mario.py:92
-        G.learn(phis, a, last)
-        img = G.predict_batch(phis, a)
-        D.learn(img, last, ref, a, phis=phis)
+        # The generator's step does not train the single-frame encoder, so its features of the real frames serve the
+        # discriminator's step as well: they are encoded once, into the first half of the discriminator's batch.
+        ob = D.obs_encoder
+        if G.obs_encoder is not ob:                              # two encoders: every step encodes for itself
+            G.learn(phis, a, last)
+            D.learn(G.predict_batch(phis, a), last, ref, a, phis=phis)
+        else:
+            if self._ob_set is None:
+                self._ob_set = ob.new_activation_set(2 * self.batch)
+            obs = ob.forward_rows(last, self._ob_set, 0)
+            G.learn(phis, a, last, obs=obs)
+            img = G.predict_batch(phis, a)
+            ob.forward_rows(img, self._ob_set, self.batch)
+            D.learn(img, last, ref, a, phis=phis, obs_set=self._ob_set)
         if self.a_pred is None and self.critic is None:
             return
         if self.a_pred is not None:

@@ -221,3 +221,29 @@ def test_blocks2x2_argument_errors():
     assert f(a.data_ptr() + 8, b.data_ptr(), 4, 6, 6, 1, None) == -5      # not 16-byte aligned
     assert f(None, b.data_ptr(), 4, 6, 6, 1, None) == -1 and f(a.data_ptr(), b.data_ptr(), 0, 6, 6, 1, None) == -1
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("c_in", [1, 4])
+def test_one_batch_encoded_in_two_calls(c_in):
+    """`forward_rows` into an activation set, half a batch at a time, then `use` + `backward`: features, the input gradient
+    and every weight gradient equal those of one `forward` over the concatenated batch bit for bit (a frame's results do
+    not depend on its batch; the gradient sums run over the same rows in the same order)."""
+    import rl_gan_amd as R
+    rng = np.random.RandomState(c_in)
+    enc = R.ConvEncoder(42, 42, c_in, R.universe_head(2), rng=rng, dense=256, bias_init=0.001)
+    a, b = torch.rand(5, 42, 42, c_in, device="cuda"), torch.rand(3, 42, 42, c_in, device="cuda")
+    d = torch.randn(8, 256, device="cuda")
+    want = enc.forward(torch.cat([a, b], 0)).clone()
+    dx_want = enc.backward(d, need_dx=True).clone()
+    g_want = [L.grad.clone() for L in enc.layers + [enc.head]]
+    for L in enc.layers + [enc.head]:
+        L.grad.zero_()
+    acts = enc.new_activation_set(8)
+    fb = enc.forward_rows(b, acts, 5)                      # the second part first: the order of the calls does not matter
+    enc.forward(torch.rand(2, 42, 42, c_in, device="cuda"))    # another pass in between leaves the set alone
+    fa = enc.forward_rows(a, acts, 0)
+    assert torch.equal(fa, want[:5]) and torch.equal(fb, want[5:])
+    assert torch.equal(enc.use(acts), want)
+    assert torch.equal(enc.backward(d, need_dx=True), dx_want)
+    for L, g in zip(enc.layers + [enc.head], g_want):
+        assert torch.equal(L.grad, g)
