@@ -356,8 +356,9 @@ class PixelGanTrainer:
             r = rows[:, self.D.a_dim + 1:self.D.a_dim + 2].contiguous()
             # the encoder has been trained by the two steps above: its features again, read from the uint8 ring in place
             # (bit-equal to encoding the gathered float32 frames)
-            phis_next = self.critic.state_encoder.forward(F.ref(self.idx, "s_"))
-            phis = self.critic.state_encoder.forward(ref)
+            # (s and s' as one batch of 2n frames: half the launches)
+            both = self.critic.state_encoder.forward(F.ref_pair(self.idx, out=self._idx2))
+            phis, phis_next = both[:self.batch], both[self.batch:]
             self.critic.learn(None, a, r, None, phis=phis, phis_next=phis_next)
             self.actor.learn(None, self.critic, phis=phis)
 
