@@ -530,8 +530,8 @@ int rlgan_deconv_fused_backward(const rlgan_deconv_t* deconv, const float* x, co
  * dz = dy * ReLU'(y)   (tf.nn.relu after the generator's first layer, Conv_model.py:455) */
 int rlgan_relu_backward(const float* dy, const float* y, float* dz, int64_t n, void* stream);
 /* dst[r][0..n_copy) = src[r][0..n_copy), dst[r][n_copy..n_copy+n_zero) = 0 for r < rows: concatenation of
- * [features, action] rows (Conv_model.py:452), channel padding of the generated 1-channel image to the 4
- * channels the convolution kernels take, and the way back (n_zero = 0). */
+ * [features, action] rows (Conv_model.py:452) with zero columns up to a 16-byte row, and column slices of such rows on
+ * the way back (n_zero = 0). */
 int rlgan_copy_cols(const float* src, int ld_src, float* dst, int ld_dst, int64_t rows, int n_copy, int n_zero, void* stream);
 /* One-channel images [n][h][w] <-> their 2x2 blocks as four channels [n][h/2][w/2][4], channel 2*dy + dx =
  * image[2Y + dy][2X + dx] (h, w even; both buffers 16-byte aligned).  to_blocks != 0: src is the image.  A 3x3
