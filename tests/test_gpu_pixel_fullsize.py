@@ -109,3 +109,50 @@ def test_critic_and_actor_steps_at_4096_rows_against_eight_steps_at_512():
         parts.append(_grads(a_layers))
     _check(full, list(zip(*parts)), 1.0, "actor (policy gradient, a sum over the rows)")
     assert all(torch.equal(b, L.canon) for b, L in zip(before, c_layers + a_layers))
+
+
+def test_whole_iteration_at_4096_rows_is_reproducible_bit_for_bit():
+    """Two learners built from the same seeds, two iterations each at the bench's batch: every variable, optimizer slot and
+    loss identical to the last bit.  No kernel of the iteration may depend on the order in which workgroups finish
+    (sums over slabs, chunks and tiles are added in a fixed order), which is also what keeps data-parallel replicas equal."""
+    import rl_gan_amd as R
+
+    def build():
+        rng = np.random.RandomState(0)
+        st = R.ConvEncoder(42, 42, 4, R.universe_head(2), rng=rng, dense=256, bias_init=0.001)
+        ob = R.single_frame_encoder(42, 2, rng=rng)
+        G = R.PixelGenerator(256, A_DIM, 1e-4, ob, rng=rng)
+        D = R.PixelDiscriminator(A_DIM, 1e-4, st, ob, rng=rng)
+        a_pred = R.StateActionPredictor(A_DIM, 1e-4, st, rng=rng)
+        actor = R.PixelActor(A_DIM, 1e-4, 1100, st, rng=rng)
+        critic = R.PixelCritic(A_DIM, 1e-4, 0.99, 1000, actor, st, rng=rng)
+        mem = R.FrameMemory(5000, (42, 42, 4), rng=R.MT19937Device(1))
+        g = torch.Generator(device="cuda").manual_seed(0)
+        for _ in range(2):
+            f = torch.randint(0, 256, (2500, 42, 42, 4), dtype=torch.uint8, device="cuda", generator=g)
+            mem.store_transitions(f, f.flip(0))
+        scal = R.DeviceMemory(5001, A_DIM + 2)
+        scal.store_rows(torch.rand(5000, A_DIM + 2, device="cuda", generator=g) * 2 - 1)
+        return R.PixelGanTrainer(mem, scal, G, D, N, a_pred=a_pred, actor=actor, critic=critic)
+
+    def state(tr):
+        out = [o.layer.canon for o in tr.G._opt + tr.D._opt + tr.a_pred._opt] + [o.m for o in tr.G._opt + tr.D._opt + tr.a_pred._opt]
+        out += [o.v for o in tr.D._opt]
+        for net in (tr.actor, tr.critic):
+            out += [o.layer.canon for o in net._opt] + [o.ms for o in net._opt] + [o.target.canon for o in net._opt]
+        return out + [tr.G.loss_out, tr.D.losses, tr.a_pred.loss_out, tr.critic.loss_out]
+
+    runs = []
+    for _ in range(2):
+        tr = build()
+        for _ in range(2):
+            tr.sample()
+            tr.step()
+        torch.cuda.synchronize()
+        runs.append([t.clone() for t in state(tr)] + [tr.idx.clone()])
+        del tr
+        torch.cuda.empty_cache()
+    assert len(runs[0]) == len(runs[1])
+    for i, (x, y) in enumerate(zip(*runs)):
+        assert torch.equal(x, y), f"state tensor {i} differs between two identical runs"
+    assert all(torch.isfinite(t).all() for t in runs[0][:-1])
