@@ -49,6 +49,7 @@ struct SrcF32 {                       // float32 activations [n][H][W][Cin]
   __device__ __forceinline__ long long image(int b) const { return (long long)((size_t)b * img); }
   __device__ __forceinline__ Raw load(long long base, size_t e) const { return *(const f32x4*)(x + base + e); }
   __device__ __forceinline__ f32x4 value(Raw r, long long) const { return r; }
+  const float* floats() const { return x; }            // host side: the plain float32 array
 };
 struct SrcU8 {                        // uint8 frame ring [slots][H*W*Cin]; image b = slot idx[b] (idx null: slot b); value = byte * scale
   using Raw = uint32_t;
@@ -66,6 +67,7 @@ struct SrcU8 {                        // uint8 frame ring [slots][H*W*Cin]; imag
     const float sc = base < 0 ? 0.f : scale;
     return f32x4{(float)(v & 255u) * sc, (float)((v >> 8) & 255u) * sc, (float)((v >> 16) & 255u) * sc, (float)(v >> 24) * sc};
   }
+  const float* floats() const { return nullptr; }
 };
 
 // Patch element table: entry q (patch elements 4q..4q+3; rowlen % 4 == 0, so the four never straddle a kernel
@@ -184,6 +186,100 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const ConvG g, const S sr
 #pragma unroll
     for (int j = 0; j < PF; ++j) { a[j] = an[j]; ka[j] = kn[j]; }
     cur = nxt; tile = ntile; chunk = nchunk;
+  }
+}
+
+// The same forward pass for float32 inputs with the number of k-groups known at compile time.  conv_fwd_kernel spends
+// more vector-ALU instructions than MFMAs on a layer with many k-groups (counted on 32 -> 32 channels, 3x3: 650 against
+// 152 per 16-pixel tile and wave: a table read, a clamp, a 64-bit address and five selects per group, register copies
+// per chunk), and on gfx950 those do not overlap with fp32 MFMAs.  Here every group's patch offset sits in a register
+// for the whole kernel, a fetch is one 32-bit add and a buffer load (scalar base, so the input must span less than
+// 2 GiB), the groups are unrolled with two register sets taking turns (NCH, the number of chunks of PF groups, is even,
+// so the turn of a tile's first chunk is always the same), and only the last group, which holds the bias row's 1 and
+// the zeros after it, selects.
+template <int NT, int NG, int PF>
+__global__ __launch_bounds__(256) void conv_fwd_static_kernel(const ConvG g, const float* __restrict__ x, const float* __restrict__ wfrag,
+                                                              float* __restrict__ y, int M, int act_elu) {
+  constexpr int NCH = (NG + PF - 1) / PF;
+  static_assert(NCH % 2 == 0, "two register sets take turns: an even number of chunks per tile");
+  extern __shared__ __attribute__((aligned(16))) float wlds[];
+  constexpr int nfrag = NG * NT * 256;
+  for (int e = threadIdx.x * 4; e < nfrag; e += 1024) *(f32x4*)(wlds + e) = *(const f32x4*)(wfrag + e);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, j = lane & 15;
+  int koff[NG];                                           // byte offset of this lane's quad of group gi from the patch's first element
+#pragma unroll
+  for (int gi = 0; gi < NG; ++gi) {
+    const int k0 = min((4 * gi + q) * 4, g.K - 4), ky = k0 / g.rowlen;      // quads past the patch: clamped, replaced below
+    koff[gi] = (ky * g.W * g.Cin + (k0 - ky * g.rowlen)) * 4;
+  }
+  const int kl = (4 * (NG - 1) + q) * 4;                  // the last group's quad: data, the bias row's 1, or zeros
+  const bool last_data = kl < g.K;
+  const float last_one = kl == g.K ? 1.f : 0.f;
+  __syncthreads();
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, 0x7fffffff, 0x00020000);
+  const int ntiles = (M + 15) / 16, per_wg = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int t_end = min(ntiles, ((int)blockIdx.x + 1) * per_wg);
+  int tile = __builtin_amdgcn_readfirstlane((int)blockIdx.x * per_wg + wave);
+  if (tile >= t_end) return;                              // no barrier follows
+  const float* wl = wlds + lane * 4;
+  const int img_bytes = g.H * g.W * g.Cin * 4;
+  auto first = [&](int t) {                               // byte offset of the patch of this lane's pixel of tile t
+    const int p = min(t * 16 + j, M - 1);
+    const int b = fdiv(p, g.dHoWo), r = p - b * (g.Ho * g.Wo), oy = fdiv(r, g.dWo), ox = r - oy * g.Wo;
+    return b * img_bytes + (oy * g.W + ox) * (g.s * g.Cin * 4);
+  };
+  f32x4 a[2][PF];
+  auto fetch = [&](int at, int c, f32x4 (&dst)[PF]) {     // chunk c (a compile-time constant after unrolling) of the patch at `at`
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int gi = min(c * PF + u, NG - 1);
+      dst[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, at + koff[gi], 0, 0));
+    }
+  };
+  int cur = first(tile);
+  fetch(cur, 0, a[0]);
+  for (;;) {
+    const int ntile = tile + 4;
+    const bool more = ntile < t_end;                      // uniform: tile is a scalar
+    const int nxt = first(min(ntile, t_end - 1));         // always computed and fetched from (a clamped tile at the end): no branch around loads
+    f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      if (c + 1 < NCH) fetch(cur, c + 1, a[(c + 1) & 1]);
+      else fetch(nxt, 0, a[0]);
+      __builtin_amdgcn_sched_barrier(0);                  // keep the fetches ahead of this chunk's products
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        const int gi = c * PF + u;
+        if (gi < NG) {
+          f32x4 w[NT];
+#pragma unroll
+          for (int t = 0; t < NT; ++t) w[t] = *(const f32x4*)(wl + (gi * NT + t) * 256);
+          f32x4 av = a[c & 1][u];
+          if (gi == NG - 1) av = last_data ? av : f32x4{last_one, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[t][m], av[m], acc[t], 0, 0, 0);
+          }
+        }
+      }
+    }
+    const int p = tile * 16 + j;
+    if (p < M) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int n0 = 16 * t + q * 4;
+        if (n0 >= g.Cout) continue;
+        f32x4 v = acc[t];
+        if (act_elu) v = f32x4{elu_f(v[0]), elu_f(v[1]), elu_f(v[2]), elu_f(v[3])};
+        *(f32x4*)(y + (size_t)p * g.Cout + n0) = v;
+      }
+    }
+    if (!more) break;
+    cur = nxt; tile = ntile;
   }
 }
 
@@ -1125,6 +1221,21 @@ int launch_fwd(const ConvG& g, const S& src, const float* wfrag, float* y, int n
   const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds));
   const dim3 grid(std::min(cdiv(cdiv(M, 16), 4), 256 * per_cu)), block(256);
   hipStream_t st = (hipStream_t)stream;
+  if (const float* xf = src.floats()) {
+    // float32 input of less than 2 GiB and a layer whose group count has an unrolled form
+    const bool small = (long long)n_images * g.H * g.W * g.Cin * 4 < 0x7fffffffll && g.K >= 4 && !((uintptr_t)xf & 15);
+#define RLGAN_FWS(NTV, NGV, PFV)                                                                                         \
+    if (small && g.NG == NGV && g.NT == NTV) {                                                                           \
+      hipLaunchKernelGGL((conv_fwd_static_kernel<NTV, NGV, PFV>), grid, block, (size_t)NGV * NTV * 1024, st, g, xf, wfrag, y, M, act_elu); \
+      return launched();                                                                                                 \
+    }
+    RLGAN_FWS(2, 19, 5)      // 32 -> 32 channels, 3x3 (the universe head's layers after the first)
+    RLGAN_FWS(1, 7, 2)       // 4 -> 8, 5x5 (the doom head's first layer)
+    RLGAN_FWS(1, 5, 3)       // 8 -> 16, 3x3
+    RLGAN_FWS(2, 10, 3)      // 16 -> 32, 3x3
+    RLGAN_FWS(4, 19, 5)      // 32 -> 64, 3x3
+#undef RLGAN_FWS
+  }
 #define RLGAN_FW(NTV)                                                                                              \
   {                                                                                                                \
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)conv_fwd_kernel<NTV, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
