@@ -34,7 +34,6 @@ inline bool make_conv(const rlgan_conv_t* c, ConvG& g) {
   return true;
 }
 
-__device__ __forceinline__ float elu_f(float z) { return z > 0.f ? z : expm1f(z); }
 __device__ __forceinline__ float elu_d(float y) { return y > 0.f ? 1.f : y + 1.f; }   // ELU' from the layer output
 
 // Where a layer's input comes from.  `image(b)` = offset of image b in elements (negative: no such image, its

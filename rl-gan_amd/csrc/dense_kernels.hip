@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
         const int row = m0 + wm + 16 * s + q4 + r;
         if (row < g.M && col < g.N) {
           float v = acc[s][t][r];
-          if (g.act == 1) v = v > 0.f ? v : expm1f(v);
+          if (g.act == 1) v = elu_f(v);
           else if (g.act == 2) v = fmaxf(v, 0.f);
           else if (g.act == 3) v = __builtin_amdgcn_fmed3f(v, 0.f, 6.f);
           else if (g.act == 4) v = tanhf(v);
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void split_sum_kernel(const float* __restrict_
 #pragma unroll
     for (int u = 0; u < 8; ++u) if (z0 + u < n_slabs) v += t[u];
   }
-  if (act == 1) v = v > 0.f ? v : expm1f(v);
+  if (act == 1) v = elu_f(v);
   else if (act == 2) v = fmaxf(v, 0.f);
   else if (act == 3) v = __builtin_amdgcn_fmed3f(v, 0.f, 6.f);
   else if (act == 4) v = tanhf(v);

@@ -247,3 +247,18 @@ def test_one_batch_encoded_in_two_calls(c_in):
     assert torch.equal(enc.backward(d, need_dx=True), dx_want)
     for L, g in zip(enc.layers + [enc.head], g_want):
         assert torch.equal(L.grad, g)
+
+
+def test_elu_absolute_accuracy():
+    """tf.nn.elu on the device is exp(z) - 1 through the hardware's exp2, the form TensorFlow's own kernel has: within
+    1.5e-7 of the float64 value for every z (about an ulp of the exponential), over twelve decades of |z|."""
+    import rl_gan_amd as R
+    z = np.concatenate([-np.logspace(-9, np.log10(30.0), 4000), np.linspace(-2, 2, 1001), [0.0, -0.0, -88.0, -200.0]]).astype(np.float32)
+    n = 64
+    z = np.resize(z, (z.size + n - 1) // n * n).reshape(-1, n)
+    L = R.DenseLayer(n, n, kernel=np.eye(n), bias=np.zeros(n))
+    y = L.forward(torch.from_numpy(z).cuda()).cpu().numpy().astype(np.float64)
+    z64 = z.astype(np.float64)
+    want = np.where(z64 > 0, z64, np.expm1(z64))
+    assert np.abs(y - want).max() <= 1.5e-7
+    assert (y[z > 0] == z[z > 0]).all() and (y >= -1.0).all()
