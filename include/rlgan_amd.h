@@ -464,6 +464,12 @@ int rlgan_column_sums(const float* dy, const float* y_relu, int64_t rows, int32_
  * GPU share that array: two calls whose kernels may overlap on one GPU (different streams) race; calls on one
  * stream, or ordered by events, do not. */
 int rlgan_column_sums_noalloc(const float* dy, const float* y_relu, int64_t rows, int32_t n_cols, float* out, void* stream);
+/* Set-up for rlgan_column_sums_noalloc on the CURRENT device: looks up the device address of the fixed scratch array
+ * (one symbol lookup, which may load the library's code object on that GPU).  Call it once per GPU, outside HIP graph
+ * capture, before the first allocation-free call that is recorded into a graph; a call that finds the address missing
+ * still looks it up itself (for the device that owns `stream`), which is fine outside capture only.  No counterpart in
+ * the reference.  Allocates nothing. */
+int rlgan_noalloc_init(void);
 /* dst[i] = map[i] >= 0 ? src[map[i]] : 0   (a gradient image back into canonical parameter order) */
 int rlgan_gather_map(const float* src, const int32_t* map, int32_t n, float* dst, void* stream);
 

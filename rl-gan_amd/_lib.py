@@ -203,6 +203,7 @@ PROTOTYPES = {
     "rlgan_deconv_fused_backward": [C.POINTER(Deconv), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "rlgan_column_sums": [_vp, _vp, C.c_int64, _i, _vp, _vp, _vp],
     "rlgan_column_sums_noalloc": [_vp, _vp, C.c_int64, _i, _vp, _vp],
+    "rlgan_noalloc_init": [],
     "rlgan_gather_map": [_vp, _vp, _i, _vp, _vp],
     "rlgan_relu_backward": [_vp, _vp, _vp, C.c_int64, _vp],
     "rlgan_copy_cols": [_vp, _i, _vp, _i, C.c_int64, _i, _i, _vp],

@@ -127,7 +127,7 @@ class ConvLayer:
         n = x.shape[0]
         use_mfma = self.wdx is not None and not self.gather_dx
         # ELU' is applied by the consumers as they read dy (no pass of its own) unless the gather kernel runs
-        fuse = act and (use_mfma or self.c_in == 4 or not need_dx)     # four input channels: a kernel of its own, ELU' included
+        fuse = act and (use_mfma or (self.c_in == 4 and self.conv.stride <= 4) or not need_dx)   # four input channels at stride <= 4: a kernel of its own, ELU' included
         dz, yel = dy, (y.data_ptr() if fuse else None)
         if act and not fuse:
             dz = torch.empty_like(dy)
@@ -205,6 +205,26 @@ class SingleFrameConv(ConvLayer):
             for kx in range(3):
                 kern[ky, kx, 0] = blocks[ky // 2, kx // 2, 2 * (ky % 2) + kx % 2]
         return kern, f[nk:]
+
+    def _tap_index(self) -> np.ndarray:
+        """Position in the flat block layout [2, 2, 4, f] + bias of every entry of the reference's flat [3, 3, 1, f] + bias."""
+        f = self.c_out
+        pos = np.arange(16 * f).reshape(2, 2, 4, f)
+        taps = [pos[ky // 2, kx // 2, 2 * (ky % 2) + kx % 2] for ky in range(3) for kx in range(3)]
+        return np.concatenate([np.concatenate(taps), 16 * f + np.arange(f)])
+
+    def to_frame_layout(self, t: torch.Tensor) -> np.ndarray:
+        """A parameter-shaped vector of this layer (canon, gradient, optimizer slot) as the reference lays it out:
+        kernel [3, 3, 1, f] flat, then the bias: 10 f numbers."""
+        return t.detach().cpu().numpy()[self._tap_index()]
+
+    def from_frame_layout(self, a: np.ndarray) -> torch.Tensor:
+        """The inverse of `to_frame_layout`; the seven block entries outside the 3x3 window are zero."""
+        a = np.asarray(a)
+        assert a.shape == (10 * self.c_out,), a.shape
+        out = np.zeros(17 * self.c_out, dtype=a.dtype)
+        out[self._tap_index()] = a
+        return torch.from_numpy(out)
 
     def frame_kernel_grad(self) -> Tuple[np.ndarray, np.ndarray]:
         """self.grad in the reference's shapes: (d kernel [3, 3, 1, f], d bias)."""

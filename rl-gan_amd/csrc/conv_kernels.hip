@@ -1225,6 +1225,8 @@ int launch_fwd(const ConvG& g, const S& src, const float* wfrag, float* y, int n
     const bool small = (long long)n_images * g.H * g.W * g.Cin * 4 < 0x7fffffffll && g.K >= 4 && !((uintptr_t)xf & 15);
 #define RLGAN_FWS(NTV, NGV, PFV)                                                                                         \
     if (small && g.NG == NGV && g.NT == NTV) {                                                                           \
+      if ((size_t)NGV * NTV * 1024 > 64 * 1024)                                                                          \
+        (void)hipFuncSetAttribute((const void*)conv_fwd_static_kernel<NTV, NGV, PFV>, hipFuncAttributeMaxDynamicSharedMemorySize, NGV * NTV * 1024); \
       hipLaunchKernelGGL((conv_fwd_static_kernel<NTV, NGV, PFV>), grid, block, (size_t)NGV * NTV * 1024, st, g, xf, wfrag, y, M, act_elu); \
       return launched();                                                                                                 \
     }

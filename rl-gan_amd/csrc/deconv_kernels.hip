@@ -263,21 +263,34 @@ __global__ void one_minus_sigmoid_kernel(const float* __restrict__ logits, int l
 
 inline int launched() { return (int)hipGetLastError(); }
 
-// device address of `scratch` on the current GPU, looked up once per device
+// device address of `scratch` per GPU: every GPU holds its own copy of the array at its own address.  Looked up once per
+// device with that device current (rlgan_noalloc_init, or the first allocation-free call on the device).
 constexpr int MAX_DEVICES = 64;
 std::atomic<float*> scratch_ptr[MAX_DEVICES];
-int scratch_here(float** out) {
-  int dev = -1;
-  if (const hipError_t e = hipGetDevice(&dev)) return (int)e;
+int scratch_on(int dev, float** out) {
   if (dev < 0 || dev >= MAX_DEVICES) return RLGAN_E_ARG;
   float* p = scratch_ptr[dev].load(std::memory_order_acquire);
   if (!p) {
-    if (const hipError_t e = hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch))) return (int)e;
+    int cur = -1;
+    if (const hipError_t e = hipGetDevice(&cur)) return (int)e;
+    if (cur != dev) if (const hipError_t e = hipSetDevice(dev)) return (int)e;
+    const hipError_t e = hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch));
+    if (cur != dev) (void)hipSetDevice(cur);
+    if (e) return (int)e;
     if (!p) return (int)hipErrorInvalidSymbol;
     scratch_ptr[dev].store(p, std::memory_order_release);
   }
   *out = p;
   return 0;
+}
+// the device a stream belongs to (the current device for the null stream)
+int device_of(void* stream, int* dev) {
+  if (stream) {
+    hipDevice_t d;
+    if (hipStreamGetDevice((hipStream_t)stream, &d) == hipSuccess) { *dev = (int)d; return 0; }
+    (void)hipGetLastError();
+  }
+  return (int)hipGetDevice(dev);
 }
 
 int column_sums(const float* dy, const float* y_relu, int64_t rows, int32_t n_cols, float* partial, float* out, void* stream) {
@@ -356,8 +369,17 @@ int rlgan_column_sums_noalloc(const float* dy, const float* y_relu, int64_t rows
   if (!dy || !out || rows <= 0 || n_cols <= 0) return RLGAN_E_ARG;
   if (n_cols > COLSUM_MAX_COLS) return RLGAN_E_SCRATCH;     // a partial row would not fit its slot of the fixed array
   float* partial = nullptr;
-  if (const int rc = scratch_here(&partial)) return rc;
+  int dev = -1;
+  if (const int rc = device_of(stream, &dev)) return rc;
+  if (const int rc = scratch_on(dev, &partial)) return rc;
   return column_sums(dy, y_relu, rows, n_cols, partial, out, stream);
+}
+
+int rlgan_noalloc_init(void) {
+  int dev = -1;
+  if (const hipError_t e = hipGetDevice(&dev)) return (int)e;
+  float* p = nullptr;
+  return scratch_on(dev, &p);
 }
 
 int rlgan_gather_map(const float* src, const int32_t* map, int32_t n, float* dst, void* stream) {

@@ -104,12 +104,30 @@ class PixelAgent:
             out[name] = unit.cell.canon
         return out
 
+    def _block_layers(self) -> dict:
+        """Names of `_state_tensors` that belong to a first layer kept as a 2x2-block kernel (`SingleFrameConv`: 17 f numbers,
+        seven structural zeros per filter) -> that layer.  In a checkpoint these are written in the reference's own layout,
+        kernel [3, 3, 1, f] then bias, so the file does not depend on how the layer is run; loading puts zeros in the
+        seven entries outside the 3x3 window, for the parameters and for every optimizer slot."""
+        from .conv import SingleFrameConv
+        out = {}
+        for name, enc in (("feature_abstraction", self.state_encoder), ("single_feature_abstraction", self.obs_encoder)):
+            for i, L in enumerate(enc.layers):
+                if isinstance(L, SingleFrameConv):
+                    out[f"{name}/{i}"] = L
+        for name, net in dict(A_pred=self.A_pred, Generator=self.generator, Discriminator=self.discriminator).items():
+            for i, o in enumerate(net._opt):
+                if isinstance(o.layer, SingleFrameConv):
+                    out[f"{name}/Adam/{i}/m"] = out[f"{name}/Adam/{i}/v"] = o.layer
+        return out
+
     def save_checkpoint(self, path: str) -> None:
         """What the reference's Saver keeps (Curious_GAN_mario.py:167-172) plus what it leaves out and a bit-exact
         continuation needs: optimizer slots, counters, the exploration scale, the learning-rate pointer and NumPy's
         stream.  The replay is not saved, like the reference's."""
         st = np.random.get_state()
-        np.savez(path, **{k: v.cpu().numpy() for k, v in self._state_tensors().items()},
+        blocked = self._block_layers()
+        np.savez(path, **{k: (blocked[k].to_frame_layout(v) if k in blocked else v.cpu().numpy()) for k, v in self._state_tensors().items()},
                  **{"host/var": self.var, "host/total_steps": self.total_steps, "host/lr_pointer": self.lr_pointer,
                     "host/np_keys": st[1], "host/np_pos": st[2], "host/np_gauss": np.array([st[3], st[4]])})
 
@@ -119,8 +137,13 @@ class PixelAgent:
             missing = [k for k in tensors if k not in f.files]
             if missing:
                 raise KeyError(f"checkpoint lacks {missing[:3]}...")
+            blocked = self._block_layers()
             for k, t in tensors.items():
                 a = f[k]
+                if k in blocked:                                   # kept in the reference's [3, 3, 1, f] + bias layout in the file
+                    if a.shape != (10 * blocked[k].c_out,):
+                        raise ValueError(f"{k}: checkpoint has shape {a.shape}, the reference layout is {(10 * blocked[k].c_out,)}")
+                    a = blocked[k].from_frame_layout(a).numpy()
                 if a.shape != tuple(t.shape):
                     raise ValueError(f"{k}: checkpoint has shape {a.shape}, the model {tuple(t.shape)}")
                 t.copy_(torch.from_numpy(a))

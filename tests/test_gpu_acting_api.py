@@ -165,10 +165,13 @@ def test_vectorised_learner_runs_and_is_deterministic():
     assert set(np.unique(d[:, 0])) <= {0.0, 1.0} and (np.abs(d[:, 21:23]) <= 1).all()
 
 
-def test_vectorised_learner_tracks_the_oracle_loop():
-    """fill() + three iterations of the device loop against the NumPy restatement of the same loop
+@pytest.mark.parametrize("captured", [False, True], ids=["eager", "graph"])
+def test_vectorised_learner_tracks_the_oracle_loop(captured):
+    """fill() + iterations of the device loop against the NumPy restatement of the same loop
     (oracle/loop.py): ring rows, index draws, goals, episode clocks, noise scale, losses, weights.
-    Short episodes (max_ep_steps = 4) so that resets happen inside the window."""
+    Short episodes (max_ep_steps = 4) so that resets happen inside the window.  `graph`: the same with the
+    iteration recorded as HIP graphs after fill() (the launch form bench.py times) -- capture() itself runs two
+    iterations, the restatement follows them, and both directions of the counter hand-over are then replayed twice."""
     import rl_gan_amd as R
     from gpu_util import close
     from oracle_util import load_weights
@@ -184,7 +187,13 @@ def test_vectorised_learner_tracks_the_oracle_loop():
     L.fill()
     while O.pointer <= O.cap:
         O.act()
-    for it in range(3):
+    if captured:
+        L.capture()                  # two launched iterations, then the recording (which runs nothing)
+        for _ in range(2):
+            O.update()
+            O.act()
+        assert L._graph is not None and L.updates == 2
+    for it in range(4 if captured else 3):
         assert L.memory.pointer == O.pointer and L.ctr.tolist() == [O.pointer, O.step_count]
         np.testing.assert_array_equal(L.idx.cpu().numpy(), O.idx)                       # bit-exact draws
         close(L.memory._data[:, :25].cpu().numpy(), O.ring, what=f"ring before update {it}")
@@ -201,7 +210,57 @@ def test_vectorised_learner_tracks_the_oracle_loop():
     assert O.n_resets > 0
     close(L.actor.e.get_flat(), ag.flat("actor_e"), what="actor weights")
     close(L.critic.e.get_flat(), ag.flat("critic_e"), what="critic weights")
-    np.testing.assert_array_equal(L.actor.t.get_flat(), L.actor.e.get_flat())       # copied on calls 0 and 2
+    if not captured:
+        np.testing.assert_array_equal(L.actor.t.get_flat(), L.actor.e.get_flat())   # copied on calls 0 and 2
+    else:
+        close(L.actor.t.get_flat(), ag.flat("actor_t"), what="actor target")
+        close(L.critic.t.get_flat(), ag.flat("critic_t"), what="critic target")
+    close(L.gen.net.get_flat(), ag.flat("gen"), what="generator weights", atol=0.25e-4 * L.updates)   # Adam: sign-of-noise entries
+    close(L.disc.net.get_flat(), ag.flat("disc"), what="discriminator weights", atol=0.25e-4 * L.updates)
+
+
+def test_graph_replay_equals_eager():
+    """The launch form bench.py times -- two recorded HIP graphs replayed in turn, one per direction of the hand-over of
+    the acting step's counters and noise scale -- against the same iterations launched kernel by kernel: two learners
+    from one seed, seven iterations after the recording (each direction replayed at least three times), everything the
+    loop owns bit for bit: replay ring, index draw, counters, noise scale, environments, losses, the six networks and
+    their optimizer slots."""
+    import rl_gan_amd as R
+    cfg = R.LearnerConfig(n_env=64, batch_size=48, memory_capacity=256, seed=9, max_ep_steps=5, replace_iter_a=3, replace_iter_c=2)
+    runs = []
+    for captured in (False, True):
+        L = R.CuriousLearner(cfg)
+        L.fill()
+        if captured:
+            L.capture()
+            assert L._graph is not None and all(g is not None for g in L._graph)
+        else:
+            for _ in range(2):       # capture() runs two iterations before it records
+                L.step()
+        snaps = []
+        for it in range(7):
+            L.step()
+            torch.cuda.synchronize()
+            snaps.append(dict(
+                ring=L.memory._data.cpu().numpy().copy(), idx=L.idx.cpu().numpy().copy(), ctr=L.ctr.tolist(), cur=L._cur,
+                ctr2=L._ctr2.cpu().numpy().copy(), var2=L._var2.cpu().numpy().copy(), var=float(L.var.item()),
+                state=L.env.state32.cpu().numpy().copy(), goal=L.env.goal.cpu().numpy().copy(), ep_t=L.ep_t.cpu().numpy().copy(),
+                resets=int(L.n_resets.item()), losses=L.losses(),
+                nets=[n.get_flat().copy() for n in (L.actor.e, L.actor.t, L.critic.e, L.critic.t, L.gen.net, L.disc.net)],
+                slots=[t.cpu().numpy().copy() for t in (L.actor.ms, L.critic.ms, L.critic.ms_actor, L.gen.m, L.gen.v, L.disc.m, L.disc.v)],
+                steps=[int(t.item()) for t in (L.actor.counter, L.critic.counter, L.gen.step, L.disc.step)]))
+        assert L.updates == 9 and L.memory.pointer == L.ctr.tolist()[0]
+        runs.append(snaps)
+    for it, (e, g) in enumerate(zip(*runs)):
+        for key in ("ctr", "cur", "var", "resets", "steps", "losses"):
+            assert e[key] == g[key], (it, key, e[key], g[key])
+        for key in ("ring", "idx", "ctr2", "var2", "state", "goal", "ep_t"):
+            np.testing.assert_array_equal(e[key], g[key], err_msg=f"iteration {it}: {key}")
+        for k, (a, b) in enumerate(zip(e["nets"], g["nets"])):
+            np.testing.assert_array_equal(a, b, err_msg=f"iteration {it}: network {k}")
+        for k, (a, b) in enumerate(zip(e["slots"], g["slots"])):
+            np.testing.assert_array_equal(a, b, err_msg=f"iteration {it}: slot {k}")
+    assert runs[0][-1]["resets"] > 0 and all(np.isfinite(v) for v in runs[0][-1]["losses"].values())
 
 
 def test_update_without_acting_draws_fresh_indices():

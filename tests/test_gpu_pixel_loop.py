@@ -83,3 +83,29 @@ def test_checkpoint_continues_bit_for_bit(tmp_path):
     assert la == agent2_losses
     for (ka, ta), (kb, tb) in zip(agent._state_tensors().items(), other._state_tensors().items()):
         assert ka == kb and torch.equal(ta, tb), ka
+
+
+def test_checkpoint_keeps_the_single_frame_kernel_in_the_reference_shape(tmp_path):
+    """The single-frame encoder's first layer runs on 2x2 blocks (17 f numbers, seven structural zeros per filter); the file
+    holds it, and its Adam slots, as the reference's [3, 3, 1, f] kernel + bias (10 f numbers), and loading leaves zeros
+    in the seven entries whatever the file held around them."""
+    import rl_gan_amd as R
+    agent, _ = _run(seed=4)
+    path = str(tmp_path / "pixel.npz")
+    agent.save_checkpoint(path)
+    L = agent.obs_encoder.layers[0]
+    f = L.c_out
+    names = agent._block_layers()
+    assert "single_feature_abstraction/0" in names and sum(k.endswith("/m") for k in names) >= 1
+    with np.load(path) as z:
+        kern, bias = L.kernel_bias()
+        np.testing.assert_array_equal(z["single_feature_abstraction/0"], np.concatenate([kern.ravel(), bias]))
+        for k in names:
+            assert z[k].shape == (10 * f,), k
+    other = R.PixelAgent(R.PixelSettings(MEMORY_CAPACITY=12, BATCH_SIZE=8, MAX_EP_STEPS=10, LR_DECAY_LIST=[20, 25], SEED=99))
+    other.load_checkpoint(path)
+    outside = (other.obs_encoder.layers[0].mask == 0)
+    for k, t in other._state_tensors().items():
+        if k in names:
+            assert not t[outside].any(), k
+            assert torch.equal(t, agent._state_tensors()[k]), k

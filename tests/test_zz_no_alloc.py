@@ -50,3 +50,37 @@ def test_beyond_the_scratch_is_refused():
     assert b"n_cols <= 256" in _lib.lib.rlgan_error_string(rc)
     assert _lib.lib.rlgan_column_sums_noalloc(None, None, 4, 8, x.data_ptr(), None) == -1
     assert _lib.lib.rlgan_column_sums_noalloc(x.data_ptr(), None, 0, 8, x.data_ptr(), None) == -1
+
+
+def test_recorded_in_a_graph_after_the_init_call():
+    """The callers the entry point is for include code under HIP graph capture: after `rlgan_noalloc_init` (the symbol
+    lookup, outside capture) the call is recorded, the graph replayed twice on fresh inputs, and every replay gives the
+    bits of rlgan_column_sums."""
+    _lib.check(_lib.lib.rlgan_noalloc_init(), "rlgan_noalloc_init")
+    rows, cols = 30000, 64
+    dy = torch.randn(rows, cols, device="cuda")
+    y = torch.randn(rows, cols, device="cuda")
+    part = torch.empty(512 * cols, device="cuda")
+    ref = torch.empty(cols, device="cuda")
+    got = torch.full((cols,), float("nan"), device="cuda")
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):       # one launched call first, as for any kernel that is going to be recorded
+        _lib.check(_lib.lib.rlgan_column_sums_noalloc(dy.data_ptr(), y.data_ptr(), rows, cols, got.data_ptr(), side.cuda_stream), "warm-up")
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        st = torch.cuda.current_stream().cuda_stream
+        _lib.check(_lib.lib.rlgan_column_sums_noalloc(dy.data_ptr(), y.data_ptr(), rows, cols, got.data_ptr(), st), "recorded call")
+    for seed in (1, 2):
+        g = torch.Generator(device="cuda").manual_seed(seed)
+        dy.copy_(torch.randn(rows, cols, device="cuda", generator=g))
+        y.copy_(torch.randn(rows, cols, device="cuda", generator=g))
+        got.fill_(float("nan"))
+        graph.replay()
+        _lib.check(_lib.lib.rlgan_column_sums(dy.data_ptr(), y.data_ptr(), rows, cols, part.data_ptr(), ref.data_ptr(),
+                                              torch.cuda.current_stream().cuda_stream), "rlgan_column_sums")
+        torch.cuda.synchronize()
+        assert np.all(np.isfinite(ref.cpu().numpy()))
+        np.testing.assert_array_equal(got.cpu().numpy(), ref.cpu().numpy())
