@@ -21,13 +21,17 @@ struct CriticArgs {
   float* loss_parts;
   int32_t* counter;           // optional: += 1 per launch (t_replace_counter, DDPG.py:64,178)
 };
-constexpr int CRITIC_LDS = PART_FLOATS + SET_FLOATS + O_FLOATS + 64 + STAGE_FLOATS;
+template <int NW> constexpr int critic_lds() { return PartL<NW>::FLOATS + SET_FLOATS + O_FLOATS + 64 + STAGE_FLOATS; }
 
+// NW: waves of the workgroup (4 in the single-step kernels, 8 in the fused phases, where two tiles per compute unit
+// then make four waves per SIMD instead of two; the results do not depend on it)
+template <int NW>
 __device__ __forceinline__ void critic_tile(const CriticArgs& A, float* smem, int tile) {
   if (tile == 0 && threadIdx.x == 0 && A.counter) A.counter[0] += 1;   // nothing in this launch reads it
+  const bool tile_thread = NW == 4 || threadIdx.x < 256;              // one thread per element of a 16x16 tile
   float* part = smem;
-  TileSet ts = carve_set(smem + PART_FLOATS);
-  float* dsave = smem + PART_FLOATS + SET_FLOATS;   // [16][LD_O]
+  TileSet ts = carve_set(smem + PartL<NW>::FLOATS);
+  float* dsave = smem + PartL<NW>::FLOATS + SET_FLOATS;   // [16][LD_O]
   float* small = dsave + O_FLOATS;                  // y[16], dq[16], scratch[16]
   float* stage = small + 64;                        // [16][STAGE_LD]: s | a | r | s' of the tile's rows
   const Tiles t = mk(ts, part);
@@ -37,28 +41,28 @@ __device__ __forceinline__ void critic_tile(const CriticArgs& A, float* smem, in
   const float* st_s = stage; const float* st_a = stage + S; const float* st_r = stage + S + Ad; const float* st_sn = stage + S + Ad + 1;
 
   // target action a' = actor_target(s')
-  FwdPre<NET_ACTOR> p_at; p_at.issue(A.actor_t.wf + A.ga.offf[0]);
-  stage_rows(stage, row0, A.n_rows, gin(A.s, S), gin(A.a, Ad), gin(A.r, 1), gin(A.s_next, S));
+  FwdPre<NET_ACTOR, NW> p_at; p_at.issue(A.actor_t.wf + A.ga.offf[0]);
+  stage_rows<NW>(stage, row0, A.n_rows, gin(A.s, S), gin(A.a, Ad), gin(A.r, 1), gin(A.s_next, S));
   lds_barrier();
-  load_x0(t.x0, row0, A.n_rows, lin(st_sn, STAGE_LD, S), nil(), nil(), nullptr);
+  load_x0<NW>(t.x0, row0, A.n_rows, lin(st_sn, STAGE_LD, S), nil(), nil(), nullptr);
   lds_barrier();
-  FwdPre<NET_CRITIC> p_ct;
-  net_forward<NET_ACTOR, false>(A.actor_t.wf, A.ga, t, none, p_at, [&] { p_ct.issue(A.critic_t.wf + A.gc.offf[0]); });
+  FwdPre<NET_CRITIC, NW> p_ct;
+  net_forward<NET_ACTOR, false, NW>(A.actor_t.wf, A.ga, t, none, p_at, [&] { p_ct.issue(A.critic_t.wf + A.gc.offf[0]); });
   // q' = critic_target(s', a')
-  load_x0(t.x0, row0, A.n_rows, lin(st_sn, STAGE_LD, S), lin(t.out, LD_O, Ad), nil(), nullptr);
+  load_x0<NW>(t.x0, row0, A.n_rows, lin(st_sn, STAGE_LD, S), lin(t.out, LD_O, Ad), nil(), nullptr);
   lds_barrier();
-  FwdPre<NET_CRITIC> p_ce;
-  net_forward<NET_CRITIC, false>(A.critic_t.wf, A.gc, t, none, p_ct, [&] { p_ce.issue(A.critic_e.wf + A.gc.offf[0]); });
+  FwdPre<NET_CRITIC, NW> p_ce;
+  net_forward<NET_CRITIC, false, NW>(A.critic_t.wf, A.gc, t, none, p_ct, [&] { p_ce.issue(A.critic_e.wf + A.gc.offf[0]); });
   if (threadIdx.x < ROWS) {
     const float rew = st_r[threadIdx.x * STAGE_LD];                        // 0 beyond n_rows
     small[threadIdx.x] = rew + A.gamma * t.out[threadIdx.x * LD_O];      // y = R + gamma*q'  DDPG.py:142
   }
   // q = critic_eval(s, a)
   const ActsG wc = acts_at(A.acts_c.p, row0, A.gc.ld3);
-  load_x0(t.x0, row0, A.n_rows, lin(st_s, STAGE_LD, S), lin(st_a, STAGE_LD, Ad), nil(), wc.x0);
+  load_x0<NW>(t.x0, row0, A.n_rows, lin(st_s, STAGE_LD, S), lin(st_a, STAGE_LD, Ad), nil(), wc.x0);
   lds_barrier();
   PreAll<1> p_cb;
-  net_forward<NET_CRITIC, true>(A.critic_e.wf, A.gc, t, wc, p_ce, [&] { p_cb.issue(A.critic_e.wb + A.gc.offb[3]); });
+  net_forward<NET_CRITIC, true, NW>(A.critic_e.wf, A.gc, t, wc, p_ce, [&] { p_cb.issue(A.critic_e.wb + A.gc.offb[3]); });
   float l = 0.f;
   if (threadIdx.x < ROWS) {
     const bool valid = row0 + threadIdx.x < A.n_rows;
@@ -71,10 +75,10 @@ __device__ __forceinline__ void critic_tile(const CriticArgs& A, float* smem, in
   fill_out_col0(t.out, small + 16);
   lds_barrier();
   if (A.train_actor) {
-    FwdPre<NET_ACTOR> p_ae;
-    net_backward<NET_CRITIC, true, true>(A.critic_e.wb, A.gc, t, wc, p_cb, [&] { p_ae.issue(A.actor_e.wf + A.ga.offf[0]); });
+    FwdPre<NET_ACTOR, NW> p_ae;
+    net_backward<NET_CRITIC, true, true, NW>(A.critic_e.wb, A.gc, t, wc, p_cb, [&] { p_ae.issue(A.actor_e.wf + A.ga.offf[0]); });
     // gradient continues through the tensor actor.a: TanhGrad at the FED action (DDPG.py:148,175)
-    {
+    if (tile_thread) {
       const int r = threadIdx.x >> 4, c = threadIdx.x & 15;
       const int gr = row0 + r;
       float v = 0.f;
@@ -86,24 +90,24 @@ __device__ __forceinline__ void critic_tile(const CriticArgs& A, float* smem, in
     }
     lds_barrier();
     const ActsG wa = acts_at(A.acts_a.p, row0, A.ga.ld3);
-    load_x0(t.x0, row0, A.n_rows, lin(st_s, STAGE_LD, S), nil(), nil(), wa.x0);
+    load_x0<NW>(t.x0, row0, A.n_rows, lin(st_s, STAGE_LD, S), nil(), nil(), wa.x0);
     lds_barrier();
     PreAll<1> p_ab;
-    net_forward<NET_ACTOR, true>(A.actor_e.wf, A.ga, t, wa, p_ae, [&] { p_ab.issue(A.actor_e.wb + A.ga.offb[3]); });
-    {
+    net_forward<NET_ACTOR, true, NW>(A.actor_e.wf, A.ga, t, wa, p_ae, [&] { p_ab.issue(A.actor_e.wb + A.ga.offb[3]); });
+    if (tile_thread) {
       const int r = threadIdx.x >> 4, c = threadIdx.x & 15;
       t.out[r * LD_O + c] = dsave[r * LD_O + c];
     }
     lds_barrier();
-    net_backward<NET_ACTOR, false, true>(A.actor_e.wb, A.ga, t, wa, p_ab, NoNext{});
+    net_backward<NET_ACTOR, false, true, NW>(A.actor_e.wb, A.ga, t, wa, p_ab, NoNext{});
   } else {
-    net_backward<NET_CRITIC, false, true>(A.critic_e.wb, A.gc, t, wc, p_cb, NoNext{});
+    net_backward<NET_CRITIC, false, true, NW>(A.critic_e.wb, A.gc, t, wc, p_cb, NoNext{});
   }
 }
 
 __global__ __launch_bounds__(THREADS) void critic_step_kernel(const CriticArgs A) {
-  __shared__ __attribute__((aligned(16))) float smem[CRITIC_LDS];
-  critic_tile(A, smem, blockIdx.x);
+  __shared__ __attribute__((aligned(16))) float smem[critic_lds<4>()];
+  critic_tile<4>(A, smem, blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -117,36 +121,39 @@ struct ActorArgs {
   Acts8 acts_a;
   int32_t* counter;           // optional: += 1 per launch (t_replace_counter, DDPG.py:64,101)
 };
-constexpr int ACTOR_LDS = PART_FLOATS + 2 * SET_FLOATS;
+// both networks of this tile have a 10-wide third layer: their tile sets keep a 16-column h3 (SET10_FLOATS)
+template <int NW> constexpr int actor_lds() { return PartL<NW>::FLOATS + 2 * SET10_FLOATS; }
 
+template <int NW>
 __device__ __forceinline__ void actor_tile(const ActorArgs& A, float* smem, int tile) {
   if (tile == 0 && threadIdx.x == 0 && A.counter) A.counter[0] += 1;   // nothing in this launch reads it
+  const bool tile_thread = NW == 4 || threadIdx.x < 256;              // one thread per element of a 16x16 tile
   float* part = smem;
-  const TileSet sa = carve_set(smem + PART_FLOATS);
-  const TileSet sc = carve_set(smem + PART_FLOATS + SET_FLOATS);
+  const TileSet sa = carve_set10(smem + PartL<NW>::FLOATS);
+  const TileSet sc = carve_set10(smem + PartL<NW>::FLOATS + SET10_FLOATS);
   const Tiles ta = mk(sa, part), tc = mk(sc, part);
   const int row0 = tile * ROWS;
   const int S = A.gc.S, Ad = A.gc.A;
   const ActsG none{};
   const ActsG wa = acts_at(A.acts_a.p, row0, A.ga.ld3);
 
-  FwdPre<NET_ACTOR> p_a; p_a.issue(A.actor_e.wf + A.ga.offf[0]);
-  load_x0(ta.x0, row0, A.n_rows, gin(A.s, S), nil(), nil(), wa.x0);
+  FwdPre<NET_ACTOR, NW> p_a; p_a.issue(A.actor_e.wf + A.ga.offf[0]);
+  load_x0<NW>(ta.x0, row0, A.n_rows, gin(A.s, S), nil(), nil(), wa.x0);
   lds_barrier();
-  FwdPre<NET_CRITIC> p_c;
-  net_forward<NET_ACTOR, true>(A.actor_e.wf, A.ga, ta, wa, p_a, [&] { p_c.issue(A.critic_e.wf + A.gc.offf[0]); });   // a = actor_eval(s), live
-  load_x0(tc.x0, row0, A.n_rows, lin(ta.x0, LD_X0, S), lin(ta.out, LD_O, Ad), nil(), nullptr);   // s: from the actor's input tile
+  FwdPre<NET_CRITIC, NW> p_c;
+  net_forward<NET_ACTOR, true, NW>(A.actor_e.wf, A.ga, ta, wa, p_a, [&] { p_c.issue(A.critic_e.wf + A.gc.offf[0]); });   // a = actor_eval(s), live
+  load_x0<NW>(tc.x0, row0, A.n_rows, lin(ta.x0, LD_X0, S), lin(ta.out, LD_O, Ad), nil(), nullptr);   // s: from the actor's input tile
   lds_barrier();
   PreAll<1> p_cb;
-  net_forward<NET_CRITIC, false>(A.critic_e.wf, A.gc, tc, none, p_c, [&] { p_cb.issue(A.critic_e.wb + A.gc.offb[3]); });
-  {
+  net_forward<NET_CRITIC, false, NW>(A.critic_e.wf, A.gc, tc, none, p_c, [&] { p_cb.issue(A.critic_e.wb + A.gc.offb[3]); });
+  if (tile_thread) {
     const int r = threadIdx.x >> 4, c = threadIdx.x & 15;
     tc.out[r * LD_O + c] = (c == 0 && row0 + r < A.n_rows) ? 1.f : 0.f;   // d(sum_b q_b)/dq = 1, DDPG.py:151
   }
   lds_barrier();
   PreAll<1> p_ab;
-  net_backward<NET_CRITIC, true, false>(A.critic_e.wb, A.gc, tc, none, p_cb, [&] { p_ab.issue(A.actor_e.wb + A.ga.offb[3]); });
-  {
+  net_backward<NET_CRITIC, true, false, NW>(A.critic_e.wb, A.gc, tc, none, p_cb, [&] { p_ab.issue(A.actor_e.wb + A.ga.offb[3]); });
+  if (tile_thread) {
     const int r = threadIdx.x >> 4, c = threadIdx.x & 15;
     float v = 0.f;
     if (c < Ad) {
@@ -156,12 +163,12 @@ __device__ __forceinline__ void actor_tile(const ActorArgs& A, float* smem, int 
     ta.out[r * LD_O + c] = v;
   }
   lds_barrier();
-  net_backward<NET_ACTOR, false, true>(A.actor_e.wb, A.ga, ta, wa, p_ab, NoNext{});
+  net_backward<NET_ACTOR, false, true, NW>(A.actor_e.wb, A.ga, ta, wa, p_ab, NoNext{});
 }
 
 __global__ __launch_bounds__(THREADS) void actor_step_kernel(const ActorArgs A) {
-  __shared__ __attribute__((aligned(16))) float smem[ACTOR_LDS];
-  actor_tile(A, smem, blockIdx.x);
+  __shared__ __attribute__((aligned(16))) float smem[actor_lds<4>()];
+  actor_tile<4>(A, smem, blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -177,29 +184,30 @@ struct DiscArgs {
   float* loss_parts;
   int32_t* counter;           // optional: += 1 per launch (the optimizer's step count)
 };
-constexpr int DISC_LDS = PART_FLOATS + SET_FLOATS + 64 + STAGE_FLOATS;
+template <int NW> constexpr int disc_lds() { return PartL<NW>::FLOATS + SET_FLOATS + 64 + STAGE_FLOATS; }
 
+template <int NW>
 __device__ __forceinline__ void disc_tile(const DiscArgs& A, float* smem, int tile) {
   if (tile == 0 && threadIdx.x == 0 && A.counter) A.counter[0] += 1;   // nothing in this launch reads it
   float* part = smem;
-  const TileSet ts = carve_set(smem + PART_FLOATS);
-  float* small = smem + PART_FLOATS + SET_FLOATS;
+  const TileSet ts = carve_set(smem + PartL<NW>::FLOATS);
+  float* small = smem + PartL<NW>::FLOATS + SET_FLOATS;
   const Tiles t = mk(ts, part);
   const int row0 = tile * ROWS;
   const int S = A.gd.S, Ad = A.gd.A;
   float* stage = small + 64;                        // [16][STAGE_LD]: s | g | a | s' of the tile's rows
   float ltot = 0.f;
-  FwdPre<NET_DISC> p_f; p_f.issue(A.disc.wf + A.gd.offf[0]);
-  stage_rows(stage, row0, A.n_rows, gin(A.s, S), gin(A.g, S), gin(A.a, Ad), gin(A.s_next, S));
+  FwdPre<NET_DISC, NW> p_f; p_f.issue(A.disc.wf + A.gd.offf[0]);
+  stage_rows<NW>(stage, row0, A.n_rows, gin(A.s, S), gin(A.g, S), gin(A.a, Ad), gin(A.s_next, S));
   lds_barrier();
 #pragma unroll 1
   for (int pass = 0; pass < 2; ++pass) {
     const ActsG wd = acts_at(A.acts_d.p, pass * A.rows16 + row0, A.gd.ld3);
-    load_x0(t.x0, row0, A.n_rows, lin(stage, STAGE_LD, S), lin(stage + (pass == 0 ? S : 2 * S + Ad), STAGE_LD, S),
+    load_x0<NW>(t.x0, row0, A.n_rows, lin(stage, STAGE_LD, S), lin(stage + (pass == 0 ? S : 2 * S + Ad), STAGE_LD, S),
             lin(stage + 2 * S, STAGE_LD, Ad), wd.x0);
     lds_barrier();
     PreAll<1> p_b;
-    net_forward<NET_DISC, true>(A.disc.wf, A.gd, t, wd, p_f, [&] { p_b.issue(A.disc.wb + A.gd.offb[3]); });
+    net_forward<NET_DISC, true, NW>(A.disc.wf, A.gd, t, wd, p_f, [&] { p_b.issue(A.disc.wb + A.gd.offb[3]); });
     const float label = pass == 0 ? 0.f : A.label_real;
     float l = 0.f;
     if (threadIdx.x < ROWS) {
@@ -211,14 +219,14 @@ __device__ __forceinline__ void disc_tile(const DiscArgs& A, float* smem, int ti
     ltot += sum16_lds(small + 16, l);
     fill_out_col0(t.out, small);
     lds_barrier();
-    net_backward<NET_DISC, false, true>(A.disc.wb, A.gd, t, wd, p_b, [&] { p_f.issue(A.disc.wf + A.gd.offf[0]); });
+    net_backward<NET_DISC, false, true, NW>(A.disc.wb, A.gd, t, wd, p_b, [&] { p_f.issue(A.disc.wf + A.gd.offf[0]); });
   }
   if (threadIdx.x == 0) A.loss_parts[tile] = ltot;
 }
 
 __global__ __launch_bounds__(THREADS) void disc_step_kernel(const DiscArgs A) {
-  __shared__ __attribute__((aligned(16))) float smem[DISC_LDS];
-  disc_tile(A, smem, blockIdx.x);
+  __shared__ __attribute__((aligned(16))) float smem[disc_lds<4>()];
+  disc_tile<4>(A, smem, blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -234,29 +242,32 @@ struct GenArgs {
   float* loss_parts;
   int32_t* counter;           // optional: += 1 per launch (the optimizer's step count)
 };
-constexpr int GEN_LDS = PART_FLOATS + 2 * SET_FLOATS + 64;
+// the generator's set keeps the 64-column h3, the discriminator's the 16-column one
+template <int NW> constexpr int gen_lds() { return PartL<NW>::FLOATS + SET_FLOATS + SET10_FLOATS + 64; }
 
+template <int NW>
 __device__ __forceinline__ void gen_tile(const GenArgs& A, float* smem, int tile) {
   if (tile == 0 && threadIdx.x == 0 && A.counter) A.counter[0] += 1;   // nothing in this launch reads it
+  const bool tile_thread = NW == 4 || threadIdx.x < 256;              // one thread per element of a 16x16 tile
   float* part = smem;
-  const TileSet sg = carve_set(smem + PART_FLOATS);
-  const TileSet sd = carve_set(smem + PART_FLOATS + SET_FLOATS);
-  float* small = smem + PART_FLOATS + 2 * SET_FLOATS;
+  const TileSet sg = carve_set(smem + PartL<NW>::FLOATS);
+  const TileSet sd = carve_set10(smem + PartL<NW>::FLOATS + SET_FLOATS);
+  float* small = smem + PartL<NW>::FLOATS + SET_FLOATS + SET10_FLOATS;
   const Tiles tg = mk(sg, part), td = mk(sd, part);
   const int row0 = tile * ROWS;
   const int S = A.gg.S, Ad = A.gg.A;
   const ActsG none{};
   const ActsG wg = acts_at(A.acts_g.p, row0, A.gg.ld3);
 
-  FwdPre<NET_GEN> p_g; p_g.issue(A.gen.wf + A.gg.offf[0]);
-  load_x0(tg.x0, row0, A.n_rows, gin(A.s, S), gin(A.a, Ad), nil(), wg.x0);
+  FwdPre<NET_GEN, NW> p_g; p_g.issue(A.gen.wf + A.gg.offf[0]);
+  load_x0<NW>(tg.x0, row0, A.n_rows, gin(A.s, S), gin(A.a, Ad), nil(), wg.x0);
   lds_barrier();
-  FwdPre<NET_DISC> p_d;
-  net_forward<NET_GEN, true>(A.gen.wf, A.gg, tg, wg, p_g, [&] { p_d.issue(A.disc.wf + A.gd.offf[0]); });   // g^ = G(s, a), live
-  load_x0(td.x0, row0, A.n_rows, lin(tg.x0, LD_X0, S), lin(tg.out, LD_O, S), lin(tg.x0 + S, LD_X0, Ad), nullptr);   // s, a: from G's input tile
+  FwdPre<NET_DISC, NW> p_d;
+  net_forward<NET_GEN, true, NW>(A.gen.wf, A.gg, tg, wg, p_g, [&] { p_d.issue(A.disc.wf + A.gd.offf[0]); });   // g^ = G(s, a), live
+  load_x0<NW>(td.x0, row0, A.n_rows, lin(tg.x0, LD_X0, S), lin(tg.out, LD_O, S), lin(tg.x0 + S, LD_X0, Ad), nullptr);   // s, a: from G's input tile
   lds_barrier();
   PreAll<1> p_db;
-  net_forward<NET_DISC, false>(A.disc.wf, A.gd, td, none, p_d, [&] { p_db.issue(A.disc.wb + A.gd.offb[3]); });
+  net_forward<NET_DISC, false, NW>(A.disc.wf, A.gd, td, none, p_d, [&] { p_db.issue(A.disc.wb + A.gd.offb[3]); });
   float l = 0.f;
   if (threadIdx.x < ROWS) {
     const bool valid = row0 + threadIdx.x < A.n_rows;
@@ -268,26 +279,42 @@ __device__ __forceinline__ void gen_tile(const GenArgs& A, float* smem, int tile
   if (threadIdx.x == 0) A.loss_parts[tile] = lsum;
   fill_out_col0(td.out, small);
   lds_barrier();
-  Pre<4, 1> p_gb;
-  net_backward<NET_DISC, true, false>(A.disc.wb, A.gd, td, none, p_db, [&] { p_gb.issue(A.gen.wb + A.gg.offb[3]); });   // dX only
-  {
+  Pre<4, 1, NW> p_gb;
+  net_backward<NET_DISC, true, false, NW>(A.disc.wb, A.gd, td, none, p_db, [&] { p_gb.issue(A.gen.wb + A.gg.offb[3]); });   // dX only
+  if (tile_thread) {
     const int r = threadIdx.x >> 4, c = threadIdx.x & 15;
     tg.out[r * LD_O + c] = c < S ? td.x0[r * LD_X0 + S + c] : 0.f;      // dL/dg^ (linear output layer)
   }
   lds_barrier();
-  net_backward<NET_GEN, false, true>(A.gen.wb, A.gg, tg, wg, p_gb, NoNext{});
+  net_backward<NET_GEN, false, true, NW>(A.gen.wb, A.gg, tg, wg, p_gb, NoNext{});
 }
 
 __global__ __launch_bounds__(THREADS) void gen_step_kernel(const GenArgs A) {
-  __shared__ __attribute__((aligned(16))) float smem[GEN_LDS];
-  gen_tile(A, smem, blockIdx.x);
+  __shared__ __attribute__((aligned(16))) float smem[gen_lds<4>()];
+  gen_tile<4>(A, smem, blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------
 // fused phases: two independent steps share one launch so that every CU holds a tile of each
 // ------------------------------------------------------------------------------------------
-constexpr int PHASE1_LDS = CRITIC_LDS > DISC_LDS ? CRITIC_LDS : DISC_LDS;
-constexpr int PHASE2_LDS = ACTOR_LDS > GEN_LDS ? ACTOR_LDS : GEN_LDS;
+// Waves per tile in the fused phases.  The tiles take the count as a template parameter (4 or 8; the results are the
+// same bits).  Eight waves per tile -- sixteen per compute unit at batch 4096, four per SIMD instead of two, 128 registers
+// per wave, -DRLGAN_PNW=8 -- was built and measured: phase 1 48.5 us against 47.1, phase 2 38.0 against 37.8, wave-cycles
+// doubled, the share of them spent waiting 0.41 -> 0.47, 14 % more vector instructions (every wave repeats the per-wave
+// set-up and the narrow stages) and the matrix pipe exactly as busy as before: the launches are bound by what the pipe
+// is given, not by waves to hide latencies behind, so the default stays at four.
+#ifndef RLGAN_PNW
+#define RLGAN_PNW 4
+#endif
+constexpr int PNW = RLGAN_PNW, PTHREADS = PNW * 64;
+#if RLGAN_PNW == 8
+#define RLGAN_PHASE_BOUNDS __launch_bounds__(512, 4)      // four waves per SIMD: at most 128 registers
+#else
+#define RLGAN_PHASE_BOUNDS __launch_bounds__(256)
+#endif
+constexpr int PHASE1_LDS = critic_lds<PNW>() > disc_lds<PNW>() ? critic_lds<PNW>() : disc_lds<PNW>();
+constexpr int PHASE2_LDS = actor_lds<PNW>() > gen_lds<PNW>() ? actor_lds<PNW>() : gen_lds<PNW>();
+static_assert(2 * PHASE1_LDS * 4 <= 160 * 1024 && 2 * PHASE2_LDS * 4 <= 160 * 1024, "two workgroups per compute unit");
 
 // Role of a workgroup in a two-role launch: the first half of the grid walks the tiles of role 0, the
 // second half those of role 1.  Workgroups are placed breadth-first (one per compute unit before any
@@ -299,20 +326,20 @@ __device__ __forceinline__ void role_of(int& role, int& tile) {
   tile = role ? b - half : b;
 }
 
-__global__ __launch_bounds__(THREADS) void phase1_kernel(const CriticArgs C, const DiscArgs D) {
-  __shared__ __attribute__((aligned(16))) float smem[PHASE1_LDS];
+__global__ RLGAN_PHASE_BOUNDS void phase1_kernel(const CriticArgs C, const DiscArgs D) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];      // PHASE1_LDS floats
   int role, tile;
   role_of(role, tile);
-  if (role) disc_tile(D, smem, tile);
-  else critic_tile(C, smem, tile);
+  if (role) disc_tile<PNW>(D, smem, tile);
+  else critic_tile<PNW>(C, smem, tile);
 }
 
-__global__ __launch_bounds__(THREADS) void phase2_kernel(const ActorArgs Aa, const GenArgs G) {
-  __shared__ __attribute__((aligned(16))) float smem[PHASE2_LDS];
+__global__ RLGAN_PHASE_BOUNDS void phase2_kernel(const ActorArgs Aa, const GenArgs G) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];      // PHASE2_LDS floats
   int role, tile;
   role_of(role, tile);
-  if (role) gen_tile(G, smem, tile);
-  else actor_tile(Aa, smem, tile);
+  if (role) gen_tile<PNW>(G, smem, tile);
+  else actor_tile<PNW>(Aa, smem, tile);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -742,7 +769,9 @@ int rlgan_phase1_rows(const rlgan_critic_step_t* c, const rlgan_disc_step_t* d, 
   if (const int rc = make_critic_args(C, c)) return rc;
   if (const int rc = make_disc_args(D, d)) return rc;
   if (C.n_rows != D.n_rows) return RLGAN_E_ALIGN;
-  hipLaunchKernelGGL(phase1_kernel, dim3(2 * cdiv(C.n_rows, ROWS)), dim3(THREADS), 0, (hipStream_t)stream, C, D);
+  static const int lds_ok = (int)hipFuncSetAttribute((const void*)phase1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PHASE1_LDS * 4);
+  if (lds_ok) return lds_ok;
+  hipLaunchKernelGGL(phase1_kernel, dim3(2 * cdiv(C.n_rows, ROWS)), dim3(PTHREADS), PHASE1_LDS * 4, (hipStream_t)stream, C, D);
   return launched();
 }
 
@@ -751,7 +780,9 @@ int rlgan_phase2_rows(const rlgan_actor_step_t* a, const rlgan_gen_step_t* g, vo
   if (const int rc = make_actor_args(Aa, a)) return rc;
   if (const int rc = make_gen_args(G, g)) return rc;
   if (Aa.n_rows != G.n_rows) return RLGAN_E_ALIGN;
-  hipLaunchKernelGGL(phase2_kernel, dim3(2 * cdiv(Aa.n_rows, ROWS)), dim3(THREADS), 0, (hipStream_t)stream, Aa, G);
+  static const int lds_ok = (int)hipFuncSetAttribute((const void*)phase2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PHASE2_LDS * 4);
+  if (lds_ok) return lds_ok;
+  hipLaunchKernelGGL(phase2_kernel, dim3(2 * cdiv(Aa.n_rows, ROWS)), dim3(PTHREADS), PHASE2_LDS * 4, (hipStream_t)stream, Aa, G);
   return launched();
 }
 

@@ -157,9 +157,19 @@ template <> struct NetT<NET_PCRITIC> { static constexpr int A1 = ACT_RELU6, A2 =
 
 // ---------------------------------------------------------------- LDS carve (floats)
 
-constexpr int CHAIN_SLOTS = 5;                       // partial sums of a chained layer: four waves + the shared tile's k-group
-constexpr int SPART_OFF = CHAIN_SLOTS * ROWS * LDP;  // then four waves' partial sums of a shared tile
-constexpr int PART_FLOATS = (CHAIN_SLOTS + 4) * ROWS * LDP;
+// Partial-sum tiles of a workgroup of NW waves: one slot per wave for a chained layer plus one for the shared tile's
+// k-group, then the four sharers' partial sums of a shared tile.  Eight-wave workgroups pack the 16x16 slots (row
+// stride 16) so that two of them fit a compute unit's LDS beside two sets of activation tiles.
+template <int NW> struct PartL {
+  static constexpr int LD = NW == 4 ? LDP : 16;        // row stride of a slot
+  static constexpr int WS = ROWS * LD;                 // floats per slot
+  static constexpr int CHAIN_SLOTS = NW + 1;
+  static constexpr int SPART_OFF = CHAIN_SLOTS * WS;
+  static constexpr int FLOATS = (CHAIN_SLOTS + 4) * WS;
+};
+constexpr int CHAIN_SLOTS = PartL<4>::CHAIN_SLOTS;   // the four-wave workgroups' figures under their old names
+constexpr int SPART_OFF = PartL<4>::SPART_OFF;
+constexpr int PART_FLOATS = PartL<4>::FLOATS;
 constexpr int WIDE_FLOATS = ROWS * LD_W;
 constexpr int T3_FLOATS = ROWS * LD_3W;              // h3 tile (16 or 64 columns)
 constexpr int X0_FLOATS = ROWS * LD_X0;
@@ -248,40 +258,53 @@ struct FragSrc {
 #endif
 constexpr int RING = RLGAN_RING;
 
-template <int NT, int NG>
+template <int NT, int NG, int NW = 4>
 struct Pre {
+  static_assert(NW == 4 || NW == 8, "workgroups of four or eight waves");
   static constexpr bool SPLIT = (NT % 4 == 1) && NT > 4 && NG >= 8;
-  static constexpr int NTF = SPLIT ? NT - 1 : NT;      // tiles dealt whole
-  static constexpr int NS = SPLIT ? (NG + 3) / 4 : 0;  // k-groups of the shared tile per wave (at most)
-  static constexpr int TMAX = (NTF + 3) / 4, TMIN = NTF / 4, NHEAVY = NTF % 4;
-  static constexpr int SMIN = (TMIN > 0 ? TMIN : 1) * NG + NS;   // steps every working wave has
-  static constexpr int DS = SMIN < RING ? SMIN : RING;           // fragments in flight
-  f32x4 b[DS];
+  static constexpr int NTF = SPLIT ? NT - 1 : NT;      // tiles dealt whole, round-robin: wave w owns w, w + NW, ...
+  static constexpr int TMAX = (NTF + NW - 1) / NW, TMIN = NTF / NW, NHEAVY = NTF % NW;
+  // the shared tile's k-groups go to the waves with TMIN whole tiles (all of them when the whole tiles deal evenly):
+  // sharer sw = w - NHEAVY takes groups sw, sw + NSH, ...
+  static constexpr int NSH = SPLIT ? NW - NHEAVY : 1;
+  static_assert(!SPLIT || NSH == 4, "four sharers: four partial-sum slots, added in slot order");
+  static constexpr int NS = SPLIT ? (NG + NSH - 1) / NSH : 0;   // k-groups of the shared tile per sharer (at most)
+  // steps of a wave with T whole tiles, and the fragments it keeps in flight
+  static constexpr int steps(int T, bool share) { return T * NG + (share ? NS : 0); }
+  // (four-wave workgroups keep one depth for all their waves, that of the waves with the fewest steps)
+  static constexpr int depth(int T, bool share) {
+    const int n = NW == 4 ? steps(TMIN > 0 ? TMIN : 1, SPLIT) : steps(T, share);
+    return n < RING ? n : RING;
+  }
+  static constexpr bool HSHARE = SPLIT && NHEAVY == 0;          // do the waves with TMAX tiles share as well?
+  static constexpr int DSH = depth(TMAX, HSHARE), DSL = depth(TMIN, SPLIT);
+  static constexpr int DSMAX = DSH > DSL ? (DSH > 1 ? DSH : 1) : (DSL > 1 ? DSL : 1);
+  f32x4 b[DSMAX];
   FragSrc src;                                         // fragment blocks counted from this wave's tile 0, group 0
   int w;                                               // rotated wave index
 
   // fragment block of step s of a wave that owns T whole tiles (steps at or beyond T*NG: the shared tile's k-groups)
   template <int T>
   __device__ __forceinline__ int block(int s) const {
-    if (s < T * NG) return (s % NG) * NT + 4 * (s / NG);
-    return min(w + 4 * (s - T * NG), NG - 1) * NT + (NT - 1) - w;
+    if (s < T * NG) return (s % NG) * NT + NW * (s / NG);
+    return min(w - NHEAVY + NSH * (s - T * NG), NG - 1) * NT + (NT - 1) - w;
   }
-  template <int T>
+  template <int T, bool SHARE>
   __device__ __forceinline__ void load_first() {
 #pragma unroll
-    for (int s = 0; s < DS; ++s) b[s] = src.load(block<T>(s));
+    for (int s = 0; s < depth(T, SHARE); ++s) b[s] = src.load(block<T>(s));
   }
   __device__ __forceinline__ void issue(const float* __restrict__ wp) {
-    w = (wave_id() + (int)blockIdx.x) & 3;
+    w = (wave_id() + (int)blockIdx.x) & (NW - 1);
     src.set(wp, w);
-    if constexpr (NHEAVY == 0) load_first<TMAX>();
-    else if (w < NHEAVY) load_first<TMAX>();
-    else if constexpr (TMIN > 0) load_first<TMIN>();
+    if constexpr (NHEAVY == 0) load_first<TMAX, SPLIT>();
+    else if (w < NHEAVY) load_first<TMAX, false>();
+    else if constexpr (TMIN > 0) load_first<TMIN, SPLIT>();
   }
 };
 
 // the first layer's fragments of a network of kind KIND
-template <int KIND> using FwdPre = Pre<NT_H, first_groups(KIND)>;
+template <int KIND, int NW = 4> using FwdPre = Pre<NT_H, first_groups(KIND), NW>;
 
 struct NoPre { __device__ __forceinline__ float operator()(int, int) const { return 0.f; } };
 struct NoNext { __device__ __forceinline__ void operator()() const {} };
@@ -290,14 +313,17 @@ struct NoNext { __device__ __forceinline__ void operator()() const {} };
 //   AREG: the layer has one k-group whose A operand (all 16 rows, the 16 k) the wave already holds in `areg`;
 //         otherwise the A operands come from LDS, one float4 at xq + 16*group.
 // Two accumulators per tile take the MFMAs in turn (a dependent MFMA would wait 40 cycles instead of 32).
-template <int NT, int NG, int T, bool AREG, class P, class F, class X>
-__device__ __forceinline__ void dense_tiles(Pre<NT, NG>& p, const float* xq, const f32x4 areg, int r0, int c0, P pre, F f,
+template <int NT, int NG, int NW, int T, bool SHARE, bool AREG, class P, class F, class X>
+__device__ __forceinline__ void dense_tiles(Pre<NT, NG, NW>& p, const float* xq, const f32x4 areg, int r0, int c0, P pre, F f,
                                             float* gdst, X next, float* spart) {
-  using Q = Pre<NT, NG>;
+  using Q = Pre<NT, NG, NW>;
   static_assert(!AREG || NG == 1, "a register operand covers one k-group");
-  constexpr int DS = Q::DS, SW = T * NG, S = SW + Q::NS;
+  static_assert(!SHARE || Q::SPLIT, "only a split layer has a shared tile");
+  constexpr int NSW = SHARE ? Q::NS : 0, NSH = Q::NSH;          // this wave's steps on the shared tile; the sharers
+  constexpr int DS = Q::depth(T, SHARE), SW = T * NG, S = SW + NSW;
+  const int sw = p.w - Q::NHEAVY;                                // sharer index (meaningful when SHARE)
   // epilogue of a finished tile, cut into pieces that are issued among the MFMAs of the steps that follow
-  constexpr int PIECES = (NG >= 7 || Q::NS >= 4) ? 6 : 1;
+  constexpr int PIECES = (NG >= 7 || NSW >= 4) ? 6 : 1;
   f32x4 ap0{0.f, 0.f, 0.f, 0.f}, ap1{0.f, 0.f, 0.f, 0.f}, zp{0.f, 0.f, 0.f, 0.f}, vp{0.f, 0.f, 0.f, 0.f};
   float hvp[4] = {0.f, 0.f, 0.f, 0.f};
   int colp = 0;
@@ -316,7 +342,7 @@ __device__ __forceinline__ void dense_tiles(Pre<NT, NG>& p, const float* xq, con
   };
   // A operands are read two steps ahead of their use (an LDS read takes about as long as four MFMAs)
   auto a_at = [&](int s) {
-    return *(const f32x4*)(xq + 16 * (s < SW ? s % NG : min(p.w + 4 * (s - SW), NG - 1)));
+    return *(const f32x4*)(xq + 16 * (s < SW ? s % NG : min(sw + NSH * (s - SW), NG - 1)));
   };
   f32x4 ar[3];
   if constexpr (!AREG) {
@@ -333,7 +359,7 @@ __device__ __forceinline__ void dense_tiles(Pre<NT, NG>& p, const float* xq, con
     const int i = whole ? s / NG : T, g = whole ? s % NG : s - SW;
     if (whole && g == 0) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) hv[r] = pre(r0 + r, 16 * (p.w + 4 * i) + c0);
+      for (int r = 0; r < 4; ++r) hv[r] = pre(r0 + r, 16 * (p.w + NW * i) + c0);
       acc0 = f32x4{0.f, 0.f, 0.f, 0.f}; acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     if constexpr (!AREG) {
@@ -346,7 +372,7 @@ __device__ __forceinline__ void dense_tiles(Pre<NT, NG>& p, const float* xq, con
       acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], bv[1], acc1, 0, 0, 0);
       acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], bv[2], acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], bv[3], acc1, 0, 0, 0);
-    } else if (4 * g + 3 < NG || p.w + 4 * g < NG) {       // only the last k-group of the shared tile depends on the wave
+    } else if (NSH * g + NSH - 1 < NG || sw + NSH * g < NG) {   // only the last k-group of the shared tile depends on the wave
       s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], bv[0], s0, 0, 0, 0);
       s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], bv[1], s1, 0, 0, 0);
       s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], bv[2], s0, 0, 0, 0);
@@ -370,7 +396,7 @@ __device__ __forceinline__ void dense_tiles(Pre<NT, NG>& p, const float* xq, con
     }
     if (whole && g == NG - 1) {
       // this tile is complete: hand it to the steps that follow
-      ap0 = acc0; ap1 = acc1; colp = 16 * (p.w + 4 * i) + c0;
+      ap0 = acc0; ap1 = acc1; colp = 16 * (p.w + NW * i) + c0;
 #pragma unroll
       for (int r = 0; r < 4; ++r) hvp[r] = hv[r];
     }
@@ -382,12 +408,13 @@ __device__ __forceinline__ void dense_tiles(Pre<NT, NG>& p, const float* xq, con
   STAMP(3);
   next();
   __builtin_amdgcn_sched_barrier(0);   // the next layer's requests stay ahead of what is left of this layer's epilogue
-  if constexpr (Q::SPLIT) {
-    static_assert(Q::NS >= 4, "the shared tile's steps carry the last whole tile's epilogue");
+  if constexpr (SHARE) {
+    static_assert(Q::NS >= 4 && T >= 1, "the shared tile's steps carry the last whole tile's epilogue");
+    using PL = PartL<NW>;
     const f32x4 sz = s0 + s1;
-    float* pw = spart + p.w * (ROWS * LDP) + r0 * LDP + c0;
+    float* pw = spart + sw * PL::WS + r0 * PL::LD + c0;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) pw[r * LDP] = sz[r];
+    for (int r = 0; r < 4; ++r) pw[r * PL::LD] = sz[r];
   } else {
     // the last tile's epilogue has nothing left to hide behind
 #pragma unroll
@@ -395,14 +422,14 @@ __device__ __forceinline__ void dense_tiles(Pre<NT, NG>& p, const float* xq, con
   }
 }
 
-template <int NT, class P, class F, class X>
-__device__ __forceinline__ void dense16_rega(Pre<NT, 1>& p, const f32x4 a, P pre, F f, float* gdst, X next) {
-  using Q = Pre<NT, 1>;
+template <int NT, int NW, class P, class F, class X>
+__device__ __forceinline__ void dense16_rega(Pre<NT, 1, NW>& p, const f32x4 a, P pre, F f, float* gdst, X next) {
+  using Q = Pre<NT, 1, NW>;
   const int lane = threadIdx.x & 63;
   const int r0 = (lane >> 4) * 4, c0 = lane & 15;
-  if constexpr (Q::NHEAVY == 0) dense_tiles<NT, 1, Q::TMAX, true>(p, nullptr, a, r0, c0, pre, f, gdst, next, nullptr);
-  else if (p.w < Q::NHEAVY) dense_tiles<NT, 1, Q::TMAX, true>(p, nullptr, a, r0, c0, pre, f, gdst, next, nullptr);
-  else if constexpr (Q::TMIN > 0) dense_tiles<NT, 1, Q::TMIN, true>(p, nullptr, a, r0, c0, pre, f, gdst, next, nullptr);
+  if constexpr (Q::NHEAVY == 0) dense_tiles<NT, 1, NW, Q::TMAX, false, true>(p, nullptr, a, r0, c0, pre, f, gdst, next, nullptr);
+  else if (p.w < Q::NHEAVY) dense_tiles<NT, 1, NW, Q::TMAX, false, true>(p, nullptr, a, r0, c0, pre, f, gdst, next, nullptr);
+  else if constexpr (Q::TMIN > 0) dense_tiles<NT, 1, NW, Q::TMIN, false, true>(p, nullptr, a, r0, c0, pre, f, gdst, next, nullptr);
   else next();
   lds_barrier();
 }
@@ -418,16 +445,18 @@ __device__ __forceinline__ void dense16_rega(Pre<NT, 1>& p, const f32x4 a, P pre
 struct NoChain {
   static constexpr bool active = false;
   template <int T> __device__ __forceinline__ void run(int, const float*, int) const {}
+  __device__ __forceinline__ void run_none(int) const {}
 };
 // LAST: the wide layer's last tile is shared between the waves (Pre::SPLIT), so nobody owns it; the
 // narrow layer's last k-group is then added separately once that tile is complete (`wlast` holds its
 // fragments): run_last() into a fifth slot, or operand-swapped in registers where the consumer wants that.
-template <int TMAX, bool LAST = false>
+template <int TMAX, bool LAST = false, int NW = 4>
 struct Chain {
   static constexpr bool active = true;
-  f32x4 wc[TMAX];                                      // narrow layer's fragments of the k-groups w, w+4, ...
+  using PL = PartL<NW>;
+  f32x4 wc[TMAX];                                      // narrow layer's fragments of the k-groups w, w+NW, ...
   f32x4 wlast;                                         // ... and of its last k-group (LAST only)
-  float* part;                                         // [CHAIN_SLOTS][16][LDP]
+  float* part;                                         // [NW + 1][16][PL::LD]
   // wn: fragment image of the narrow layer (one column tile); ng: its number of k-groups
   //     nt, tile: the narrow "layer" may also be ONE column tile of a layer with nt tiles per k-group (the action columns
   //     of the pixel critic's input gradient)
@@ -435,10 +464,10 @@ struct Chain {
     FragSrc src;
     src.set(wn, tile);
 #pragma unroll
-    for (int i = 0; i < TMAX; ++i) wc[i] = src.load(min(w + 4 * i, ng - 1) * nt);
+    for (int i = 0; i < TMAX; ++i) wc[i] = src.load(min(w + NW * i, ng - 1) * nt);
     if constexpr (LAST) wlast = src.load((ng - 1) * nt);
   }
-  // the last k-group's product from the completed tile at column 16*(ng-1) of xs, into slot 4 (one wave calls this)
+  // the last k-group's product from the completed tile at column 16*(ng-1) of xs, into the slot after the waves' (one wave calls this)
   __device__ __forceinline__ void run_last(const float* xs, int ldx, int ng) {
     const int lane = threadIdx.x & 63;
     const int r0 = (lane >> 4) * 4, c0 = lane & 15;
@@ -446,11 +475,22 @@ struct Chain {
     f32x4 acc{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int m = 0; m < 4; ++m) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], wlast[m], acc, 0, 0, 0);
-    float* pw = part + 4 * (ROWS * LDP) + r0 * LDP + c0;
+    float* pw = part + NW * PL::WS + r0 * PL::LD + c0;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) pw[r * LDP] = acc[r];
+    for (int r = 0; r < 4; ++r) pw[r * PL::LD] = acc[r];
   }
-  // xs: the wide layer's output tile in LDS (row stride ldx); this wave owns its column tiles w, w+4, ...
+  // a wave without a tile of the wide layer leaves zeros in its slot
+  __device__ __forceinline__ void run_none(int w) {
+    const int lane = threadIdx.x & 63;
+    const int r0 = (lane >> 4) * 4, c0 = lane & 15;
+    float* pw = part + w * PL::WS + r0 * PL::LD + c0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) pw[r * PL::LD] = 0.f;
+  }
+  // xs: the wide layer's output tile in LDS (row stride ldx); this wave owns its column tiles w, w+NW, ...
+  // Order of additions: a four-wave workgroup's wave w owns tiles w, w+4, w+8 and leaves (t_w then t_{w+8} on one
+  // accumulator) + (t_{w+4} on another).  In an eight-wave workgroup wave w < 4 owns exactly w and w+8 and wave w+4 owns
+  // w+4: each chains its tiles on ONE accumulator and chain_sum adds the pair first, so both forms give the same bits.
   template <int T>
   __device__ __forceinline__ void run(int w, const float* xs, int ldx) {
     const int lane = threadIdx.x & 63;
@@ -458,31 +498,46 @@ struct Chain {
     f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
     f32x4 a[T];
 #pragma unroll
-    for (int i = 0; i < T; ++i) a[i] = *(const f32x4*)(xs + c0 * ldx + r0 + 16 * (w + 4 * i));
+    for (int i = 0; i < T; ++i) a[i] = *(const f32x4*)(xs + c0 * ldx + r0 + 16 * (w + NW * i));
 #pragma unroll
     for (int i = 0; i < T; ++i) {
+      constexpr int two = NW == 4 ? 1 : 0;
 #pragma unroll
-      for (int m = 0; m < 4; ++m) acc[i & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][m], wc[i][m], acc[i & 1], 0, 0, 0);
+      for (int m = 0; m < 4; ++m) acc[i & two] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][m], wc[i][m], acc[i & two], 0, 0, 0);
     }
-    const f32x4 z = acc[0] + acc[1];
-    float* pw = part + w * (ROWS * LDP) + r0 * LDP + c0;   // slot = tile owner, whatever wave that is in this workgroup
+    const f32x4 z = NW == 4 ? acc[0] + acc[1] : acc[0];
+    float* pw = part + w * PL::WS + r0 * PL::LD + c0;      // slot = tile owner, whatever wave that is in this workgroup
 #pragma unroll
-    for (int r = 0; r < 4; ++r) pw[r * LDP] = z[r];
+    for (int r = 0; r < 4; ++r) pw[r * PL::LD] = z[r];
   }
 };
-// sum of the four waves' partial tiles at (row, col .. col+3), in wave order
+// sum of the waves' partial tiles at (row, col .. col+3): four waves in wave order; eight waves as the pairs (w, w+4)
+// first, then those four in order (see Chain::run)
+template <int NW = 4>
 __device__ __forceinline__ f32x4 chain_sum4(const float* part, int row, int col) {
-  const float* q = part + row * LDP + col;
-  constexpr int WS = ROWS * LDP;
-  return ((*(const f32x4*)q + *(const f32x4*)(q + WS)) + *(const f32x4*)(q + 2 * WS)) + *(const f32x4*)(q + 3 * WS);
+  using PL = PartL<NW>;
+  const float* q = part + row * PL::LD + col;
+  constexpr int WS = PL::WS;
+  if constexpr (NW == 4) {
+    return ((*(const f32x4*)q + *(const f32x4*)(q + WS)) + *(const f32x4*)(q + 2 * WS)) + *(const f32x4*)(q + 3 * WS);
+  } else {
+    const f32x4 z0 = *(const f32x4*)q + *(const f32x4*)(q + 4 * WS), z1 = *(const f32x4*)(q + WS) + *(const f32x4*)(q + 5 * WS);
+    const f32x4 z2 = *(const f32x4*)(q + 2 * WS) + *(const f32x4*)(q + 6 * WS), z3 = *(const f32x4*)(q + 3 * WS) + *(const f32x4*)(q + 7 * WS);
+    return ((z0 + z1) + z2) + z3;
+  }
 }
+template <int NW = 4>
 __device__ __forceinline__ float chain_sum1(const float* part, int row, int col) {
-  const float* q = part + row * LDP + col;
-  constexpr int WS = ROWS * LDP;
-  return ((q[0] + q[WS]) + q[2 * WS]) + q[3 * WS];
+  using PL = PartL<NW>;
+  const float* q = part + row * PL::LD + col;
+  constexpr int WS = PL::WS;
+  if constexpr (NW == 4) return ((q[0] + q[WS]) + q[2 * WS]) + q[3 * WS];
+  else return (((q[0] + q[4 * WS]) + (q[WS] + q[5 * WS])) + (q[2 * WS] + q[6 * WS])) + (q[3 * WS] + q[7 * WS]);
 }
+template <int NW = 4>
 __device__ __forceinline__ float chain_sum1_last(const float* part, int row, int col) {   // with run_last()'s slot
-  return chain_sum1(part, row, col) + part[4 * (ROWS * LDP) + row * LDP + col];
+  using PL = PartL<NW>;
+  return chain_sum1<NW>(part, row, col) + part[NW * PL::WS + row * PL::LD + col];
 }
 
 // One dense layer of a 16-row tile, Z[16, NT*16] = X[16, NG*16] * fragments.
@@ -497,46 +552,50 @@ __device__ __forceinline__ float chain_sum1_last(const float* part, int row, int
 //         layer's Pre
 //   chain / ys, ldy: optional chained one-tile layer (see Chain); ys is the LDS tile f writes
 // Ends with a workgroup barrier on LDS (what the epilogues wrote is visible to every wave after it).
-template <int NT, int NG, class P, class F, class X, class CH>
-__device__ __forceinline__ void dense16(Pre<NT, NG>& p, const float* xs, int ldx, P pre, F f, float* gdst, X next,
+template <int NT, int NG, int NW, class P, class F, class X, class CH>
+__device__ __forceinline__ void dense16(Pre<NT, NG, NW>& p, const float* xs, int ldx, P pre, F f, float* gdst, X next,
                                         CH& chain, const float* ys, int ldy, float* spart = nullptr) {
-  using Q = Pre<NT, NG>;
+  using Q = Pre<NT, NG, NW>;
   const int lane = threadIdx.x & 63;
   const int r0 = (lane >> 4) * 4, c0 = lane & 15;
   const float* xq = xs + c0 * ldx + r0;                 // A operands of a group: one float4 at xq + 16*group
+  const f32x4 none{0.f, 0.f, 0.f, 0.f};
   STAMP(1);
   if constexpr (Q::NHEAVY == 0) {
-    dense_tiles<NT, NG, Q::TMAX, false>(p, xq, f32x4{0.f, 0.f, 0.f, 0.f}, r0, c0, pre, f, gdst, next, spart);
+    dense_tiles<NT, NG, NW, Q::TMAX, Q::SPLIT, false>(p, xq, none, r0, c0, pre, f, gdst, next, spart);
     if constexpr (CH::active) chain.template run<Q::TMAX>(p.w, ys, ldy);
   } else {
-    static_assert(!Q::SPLIT, "a shared tile leaves the whole tiles evenly dealt");
     if (p.w < Q::NHEAVY) {
-      dense_tiles<NT, NG, Q::TMAX, false>(p, xq, f32x4{0.f, 0.f, 0.f, 0.f}, r0, c0, pre, f, gdst, next, spart);
+      dense_tiles<NT, NG, NW, Q::TMAX, false, false>(p, xq, none, r0, c0, pre, f, gdst, next, spart);
       if constexpr (CH::active) chain.template run<Q::TMAX>(p.w, ys, ldy);
     } else if constexpr (Q::TMIN > 0) {
-      dense_tiles<NT, NG, Q::TMIN, false>(p, xq, f32x4{0.f, 0.f, 0.f, 0.f}, r0, c0, pre, f, gdst, next, spart);
+      dense_tiles<NT, NG, NW, Q::TMIN, Q::SPLIT, false>(p, xq, none, r0, c0, pre, f, gdst, next, spart);
       if constexpr (CH::active) chain.template run<Q::TMIN>(p.w, ys, ldy);
     } else {
+      static_assert(!Q::SPLIT, "a shared tile needs sharers with a whole tile each");
       next();
-      static_assert(!CH::active || Q::TMIN > 0, "a chained layer needs a tile on every wave");
+      if constexpr (CH::active) chain.run_none(p.w);
     }
   }
   STAMP(4);
   lds_barrier();
   if constexpr (Q::SPLIT) {
-    // the shared tile: four partial sums in slot order, epilogue, one element per thread
-    const int r = threadIdx.x >> 4, c = threadIdx.x & 15, col = 16 * (NT - 1) + c;
-    const float* q = spart + r * LDP + c;
-    constexpr int WS = ROWS * LDP;
-    const float z = ((q[0] + q[WS]) + q[2 * WS]) + q[3 * WS];
-    const float v = f(r, col, z, pre(r, col));
-    if (gdst) gdst[work_off(NT * 16, r, col)] = v;
+    // the shared tile: four partial sums in slot order, epilogue, one element per thread of the first four waves
+    using PL = PartL<NW>;
+    if (NW == 4 || threadIdx.x < 256) {
+      const int r = threadIdx.x >> 4, c = threadIdx.x & 15, col = 16 * (NT - 1) + c;
+      const float* q = spart + r * PL::LD + c;
+      constexpr int WS = PL::WS;
+      const float z = ((q[0] + q[WS]) + q[2 * WS]) + q[3 * WS];
+      const float v = f(r, col, z, pre(r, col));
+      if (gdst) gdst[work_off(NT * 16, r, col)] = v;
+    }
     lds_barrier();
   }
   STAMP(5);
 }
-template <int NT, int NG, class P, class F, class X>
-__device__ __forceinline__ void dense16(Pre<NT, NG>& p, const float* xs, int ldx, P pre, F f, float* gdst, X next,
+template <int NT, int NG, int NW, class P, class F, class X>
+__device__ __forceinline__ void dense16(Pre<NT, NG, NW>& p, const float* xs, int ldx, P pre, F f, float* gdst, X next,
                                         float* spart = nullptr) {
   NoChain nc;
   dense16(p, xs, ldx, pre, f, gdst, next, nc, nullptr, 0, spart);
@@ -572,9 +631,9 @@ struct ActsG {
 };
 
 // what the caller of net_backward requests ahead for its first stage: the fragments of W4^T
-template <int KIND> struct BwdFirst { using type = PreAll<1>; };
-template <> struct BwdFirst<NET_GEN> { using type = Pre<4, 1>; };
-template <int KIND> using BwdPre = typename BwdFirst<KIND>::type;
+template <int KIND, int NW> struct BwdFirst { using type = PreAll<1>; };
+template <int NW> struct BwdFirst<NET_GEN, NW> { using type = Pre<4, 1, NW>; };
+template <int KIND, int NW = 4> using BwdPre = typename BwdFirst<KIND, NW>::type;
 
 // forward pass of a whole network for the tile in t.x0; activations stay in t.h1..t.out and, when
 // STORE, are also written to the global work arrays for the weight-gradient pass.  `p1` holds the
@@ -582,38 +641,40 @@ template <int KIND> using BwdPre = typename BwdFirst<KIND>::type;
 // pass so the caller can request the fragments of whatever runs after this network.
 //   networks with a 10-wide third layer:  L1 | L2 + L3 partial sums (chained) | one wave: L3 total, L4
 //   generator (50-wide third layer):      L1 | L2 | L3 + L4 partial sums (chained) | L4 total
-template <int KIND, bool STORE, class X>
+template <int KIND, bool STORE, int NW = 4, class X>
 __device__ __forceinline__ void net_forward(const float* __restrict__ wf, const Geo& g, const Tiles& t, const ActsG& ws,
-                                            FwdPre<KIND>& p1, X next) {
+                                            FwdPre<KIND, NW>& p1, X next) {
   using N = NetT<KIND>;
+  using PL = PartL<NW>;
+  const bool tile_thread = NW == 4 || threadIdx.x < 256;      // one thread per element of a 16x16 tile
   constexpr int L3 = N::L3, NT3 = N::NT3;
   float* h1 = t.h1; float* h2 = t.h2; float* h3 = t.h3; float* out = t.out;
   const int lane = threadIdx.x & 63;
   const int n3 = g.N3, nout = g.NOUT;
-  Pre<NT_H, NT_H> p2;
+  Pre<NT_H, NT_H, NW> p2;
   dense16(p1, t.x0, x0_ld(KIND), NoPre{}, [=](int r, int c, float z, float) {
     const float v = c < HID ? act_f<N::A1>(z) : (c == HID ? 1.f : 0.f);
     h1[r * LD_W + c] = v;
     return v;
-  }, STORE ? ws.h1 : nullptr, [&] { p2.issue(wf + g.offf[1]); }, t.part + SPART_OFF);   // the pixel networks' 17 k-groups share the last tile
+  }, STORE ? ws.h1 : nullptr, [&] { p2.issue(wf + g.offf[1]); }, t.part + PL::SPART_OFF);   // the pixel networks' 17 k-groups share the last tile
   auto f2 = [=](int r, int c, float z, float) {
     const float v = c < HID ? act_f<N::A2>(z) : (c == HID ? 1.f : 0.f);
     h2[r * LD_W + c] = v;
     return v;
   };
   if constexpr (NT3 == 1) {
-    using Q2 = Pre<NT_H, NT_H>;
-    Chain<Q2::TMAX, Q2::SPLIT> ch;
+    using Q2 = Pre<NT_H, NT_H, NW>;
+    Chain<Q2::TMAX, Q2::SPLIT, NW> ch;
     ch.part = t.part;
     PreAll<1> p4;
     dense16(p2, h1, LD_W, NoPre{}, f2, STORE ? ws.h2 : nullptr,
-            [&] { ch.issue(wf + g.offf[2], NT_H, p2.w); p4.issue(wf + g.offf[3]); }, ch, h2, LD_W, t.part + SPART_OFF);
+            [&] { ch.issue(wf + g.offf[2], NT_H, p2.w); p4.issue(wf + g.offf[3]); }, ch, h2, LD_W, t.part + PL::SPART_OFF);
     next();
     if (wave_id() == 0) {
       // third layer: total of the partial sums, activation; the lane holds row l&15, columns 4q..4q+3,
       // which is the A operand of the fourth layer
       const int row = lane & 15, k0 = (lane >> 4) * 4;
-      f32x4 s = chain_sum4(t.part, row, k0);
+      f32x4 s = chain_sum4<NW>(t.part, row, k0);
       if constexpr (Q2::SPLIT) {
         // the last k-group (the shared tile of h2, complete since the layer's second barrier): operands
         // swapped, so the product arrives in this lane's (row, four columns) layout
@@ -640,9 +701,9 @@ __device__ __forceinline__ void net_forward(const float* __restrict__ wf, const 
     }
     lds_barrier();
   } else {
-    Pre<NT3, NT_H> p3;
-    dense16(p2, h1, LD_W, NoPre{}, f2, STORE ? ws.h2 : nullptr, [&] { p3.issue(wf + g.offf[2]); }, t.part + SPART_OFF);
-    Chain<1> ch;
+    Pre<NT3, NT_H, NW> p3;
+    dense16(p2, h1, LD_W, NoPre{}, f2, STORE ? ws.h2 : nullptr, [&] { p3.issue(wf + g.offf[2]); }, t.part + PL::SPART_OFF);
+    Chain<1, false, NW> ch;
     ch.part = t.part;
     dense16(p3, h2, LD_W, NoPre{}, [=](int r, int c, float z, float) {
       const float v = c < n3 ? act_f<N::A3>(z) : (c == n3 ? 1.f : 0.f);
@@ -650,9 +711,9 @@ __device__ __forceinline__ void net_forward(const float* __restrict__ wf, const 
       return v;
     }, STORE ? ws.h3 : nullptr, [&] { ch.issue(wf + g.offf[3], NT3, p3.w); }, ch, h3, L3);
     next();
-    {
+    if (tile_thread) {
       const int r = threadIdx.x >> 4, c = threadIdx.x & 15;
-      const float z = chain_sum1(t.part, r, c);
+      const float z = chain_sum1<NW>(t.part, r, c);
       out[r * LD_O + c] = c < nout ? act_f<N::A4>(z) : 0.f;
     }
     lds_barrier();
@@ -665,22 +726,24 @@ __device__ __forceinline__ void net_forward(const float* __restrict__ wf, const 
 // 0..15, stride LD_X0).  `p4` = fragments of W4^T requested by the caller, `next` as in net_forward.
 //   10-wide third layer: every wave computes dz3 for itself (four MFMAs with swapped operands leave it
 //   in A-operand layout in registers), then its tiles of dz2 | dz1 (+ chained dX0 partial sums) | dX0 total
-template <int KIND, bool NEED_DX0, bool STORE, class X>
+template <int KIND, bool NEED_DX0, bool STORE, int NW = 4, class X>
 __device__ __forceinline__ void net_backward(const float* __restrict__ wb, const Geo& g, const Tiles& t, const ActsG& ws,
-                                             BwdPre<KIND>& p4, X next) {
+                                             BwdPre<KIND, NW>& p4, X next) {
   using N = NetT<KIND>;
+  using PL = PartL<NW>;
+  const bool tile_thread = NW == 4 || threadIdx.x < 256;      // one thread per element of a 16x16 tile
   constexpr int L3 = N::L3, NT3 = N::NT3;
   float* h1 = t.h1; float* h2 = t.h2; float* h3 = t.h3; float* x0 = t.x0;
   const int lane = threadIdx.x & 63;
   const int r0 = (lane >> 4) * 4, c0 = lane & 15;
-  if (STORE) {
+  if (STORE && tile_thread) {
     const int r = threadIdx.x >> 4, c = threadIdx.x & 15;
     ws.dz4[work_off(16, r, c)] = t.out[r * LD_O + c];
   }
   const int n3 = g.N3;
-  Pre<NT_H, NT3> p3;
+  Pre<NT_H, NT3, NW> p3;
   p3.issue(wb + g.offb[2]);
-  Pre<NT_H, NT_H> p2;
+  Pre<NT_H, NT_H, NW> p2;
   auto f2 = [=](int r, int c, float z, float h) {
     const float v = c < HID ? z * act_d<N::A2>(h) : 0.f;
     h2[r * LD_W + c] = v;
@@ -718,25 +781,25 @@ __device__ __forceinline__ void net_backward(const float* __restrict__ wb, const
   };
   auto g1 = [=](int r, int c) { return h1[r * LD_W + c]; };
   if constexpr (NEED_DX0) {
-    using Q2 = Pre<NT_H, NT_H>;
-    Chain<Q2::TMAX, Q2::SPLIT> ch;
+    using Q2 = Pre<NT_H, NT_H, NW>;
+    Chain<Q2::TMAX, Q2::SPLIT, NW> ch;
     ch.part = t.part;
     // the arm networks have one tile of inputs; of the pixel critic's 17 only the last, which holds the action, is wanted
     const int xt = KIND >= NET_PACTOR ? g.ntb[0] - 1 : 0;
     dense16(p2, h2, LD_W, g1, f1, STORE ? ws.dz1 : nullptr, [&] { ch.issue(wb + g.offb[0], NT_H, p2.w, g.ntb[0], xt); }, ch, h1, LD_W,
-            t.part + SPART_OFF);
+            t.part + PL::SPART_OFF);
     next();
     if constexpr (Q2::SPLIT) {
       if (wave_id() == 0) ch.run_last(h1, LD_W, NT_H);      // dz1's shared tile times the last k-group of W1^T
       lds_barrier();
     }
-    {
+    if (tile_thread) {
       const int r = threadIdx.x >> 4, c = threadIdx.x & 15;
-      x0[r * x0_ld(KIND) + 16 * xt + c] = Q2::SPLIT ? chain_sum1_last(t.part, r, c) : chain_sum1(t.part, r, c);
+      x0[r * x0_ld(KIND) + 16 * xt + c] = Q2::SPLIT ? chain_sum1_last<NW>(t.part, r, c) : chain_sum1<NW>(t.part, r, c);
     }
     lds_barrier();
   } else {
-    dense16(p2, h2, LD_W, g1, f1, STORE ? ws.dz1 : nullptr, next, t.part + SPART_OFF);
+    dense16(p2, h2, LD_W, g1, f1, STORE ? ws.dz1 : nullptr, next, t.part + PL::SPART_OFF);
   }
 }
 
@@ -750,10 +813,11 @@ __device__ __forceinline__ float matin_at(const MatIn& b, int gr, int r, int c) 
   const size_t row = b.idx ? (size_t)b.idx[gr] : (size_t)gr;
   return b.p[row * b.ld + c];
 }
+template <int NW = 4>
 __device__ __forceinline__ void load_x0(float* x0, int row0, int n_rows, MatIn b0, MatIn b1, MatIn b2,
                                         float* x0_global) {
   const int k0 = b0.w + b1.w + b2.w;
-  for (int e = threadIdx.x; e < ROWS * X0_COLS; e += THREADS) {
+  for (int e = threadIdx.x; e < ROWS * X0_COLS; e += NW * 64) {
     const int r = e >> 5, c = e & 31;
     const int gr = row0 + r;
     float v = 0.f;

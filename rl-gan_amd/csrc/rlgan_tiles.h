@@ -24,7 +24,9 @@ __device__ __forceinline__ float mat_at(const Mat& m, int gr, int c) {
 // the same rows reads them from here (lin(stage + column, STAGE_LD, width)) instead of paying a chain of
 // two global round trips (row index, then row) at the start of every pass.  No barrier inside.
 constexpr int STAGE_LD = 32, STAGE_FLOATS = ROWS * STAGE_LD;
+template <int NW = 4>
 __device__ __forceinline__ void stage_rows(float* stage, int row0, int n_rows, MatIn b0, MatIn b1, MatIn b2, MatIn b3) {
+  constexpr int NTHR = NW * 64;
   const int e0 = b0.w, e1 = e0 + b1.w, e2 = e1 + b2.w, e3 = e2 + b3.w;
   const bool all_idx = b0.idx && (!b1.w || b1.idx) && (!b2.w || b2.idx) && (!b3.w || b3.idx);
   const bool no_idx = !b0.idx && !b1.idx && !b2.idx && !b3.idx;
@@ -33,13 +35,13 @@ __device__ __forceinline__ void stage_rows(float* stage, int row0, int n_rows, M
     // The usual case, without a branch around any load: which block a lane reads is a matter of selects, so the
     // index loads of all its elements go out together, then the row loads -- two memory round trips in all.
     // (One branch per block made it eight, each waited for where the branches join.)
-    constexpr int PER = STAGE_FLOATS / THREADS;
+    constexpr int PER = STAGE_FLOATS / NTHR;
     long long row[PER];
     const float* src[PER];
     bool ok[PER];
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
-      const int e = threadIdx.x + i * THREADS, r = e / STAGE_LD, c = e % STAGE_LD, gr = row0 + r;
+      const int e = threadIdx.x + i * NTHR, r = e / STAGE_LD, c = e % STAGE_LD, gr = row0 + r;
       ok[i] = gr < n_rows && c < e3;
       const int which = ok[i] ? (c >= e0) + (c >= e1) + (c >= e2) : 0;
       const float* p = which == 0 ? b0.p : which == 1 ? b1.p : which == 2 ? b2.p : b3.p;
@@ -54,11 +56,11 @@ __device__ __forceinline__ void stage_rows(float* stage, int row0, int n_rows, M
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
       const float v = src[i][row[i]];
-      stage[threadIdx.x + i * THREADS] = ok[i] ? v : 0.f;
+      stage[threadIdx.x + i * NTHR] = ok[i] ? v : 0.f;
     }
     return;
   }
-  for (int e = threadIdx.x; e < STAGE_FLOATS; e += THREADS) {
+  for (int e = threadIdx.x; e < STAGE_FLOATS; e += NTHR) {
     const int r = e / STAGE_LD, c = e % STAGE_LD;
     const int gr = row0 + r;
     float v = 0.f;
@@ -85,6 +87,18 @@ __device__ __forceinline__ TileSet carve_set(float* base) {
   return s;
 }
 
+// the same for a network whose third layer is 10 wide (actor, critic, discriminator): h3 is a 16-column tile
+constexpr int SET10_FLOATS = X0_FLOATS + 2 * WIDE_FLOATS + 2 * O_FLOATS;
+__device__ __forceinline__ TileSet carve_set10(float* base) {
+  TileSet s;
+  s.x0 = base; base += X0_FLOATS;
+  s.h1 = base; base += WIDE_FLOATS;
+  s.h2 = base; base += WIDE_FLOATS;
+  s.h3 = base; base += O_FLOATS;
+  s.out = base;
+  return s;
+}
+
 // sum of v over the first 16 threads' values, returned to thread 0 (deterministic order)
 __device__ __forceinline__ float sum16_lds(float* scratch16, float v) {
   if (threadIdx.x < ROWS) scratch16[threadIdx.x] = v;
@@ -98,8 +112,9 @@ __device__ __forceinline__ float sum16_lds(float* scratch16, float v) {
   return s;
 }
 
-// a [16][16] "dz4" tile whose column 0 comes from v16 (LDS), zeros elsewhere
+// a [16][16] "dz4" tile whose column 0 comes from v16 (LDS), zeros elsewhere (threads beyond the tile's 256 do nothing)
 __device__ __forceinline__ void fill_out_col0(float* out, const float* v16) {
+  if (threadIdx.x >= 256) return;
   const int r = threadIdx.x >> 4, c = threadIdx.x & 15;
   out[r * LD_O + c] = (c == 0) ? v16[r] : 0.f;
 }
