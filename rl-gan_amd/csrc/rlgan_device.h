@@ -386,12 +386,13 @@ __device__ __forceinline__ void dense_tiles(Pre<NT, NG, NW>& p, const float* xq,
       } else if (whole) {
         // from the second step on: the first piece reads the accumulators, and the tile's last MFMA has left the
         // pipe only a step after it was issued
-        if (g >= 1 && g <= PIECES) piece(g - 1);
+        // All six pieces in ONE step: a lone vector instruction between two MFMAs costs the pipe about 6 cycles, one of
+        // a run about 2.5 (tools/valu_mix.hip), so the epilogue is issued as a block inside the next tile's second step
+        // instead of a piece per step (headline step 0.1711 -> 0.1703 ms on one box, A B A B).
+        if (g == 1) { piece(0); piece(1); piece(2); piece(3); piece(4); piece(5); }
       } else {
-        // the steps of the shared tile take the six pieces: none, 0-2, 3-4, 5
-        if (g == 1) { piece(0); piece(1); piece(2); }
-        if (g == 2) { piece(3); piece(4); }
-        if (g == 3) piece(5);
+        // the shared tile's second step takes them all
+        if (g == 1) { piece(0); piece(1); piece(2); piece(3); piece(4); piece(5); }
       }
     }
     if (whole && g == NG - 1) {
