@@ -47,6 +47,10 @@ struct SrcF32 {                       // float32 activations [n][H][W][Cin]
   size_t img;
   __device__ __forceinline__ long long image(int b) const { return (long long)((size_t)b * img); }
   __device__ __forceinline__ Raw load(long long base, size_t e) const { return *(const f32x4*)(x + base + e); }
+  // the same fetch for data read once and never again (kept out of the way of what the caches hold for others)
+  __device__ __forceinline__ Raw load_stream(long long base, size_t e) const {
+    return __builtin_nontemporal_load((const f32x4*)(x + base + e));
+  }
   __device__ __forceinline__ f32x4 value(Raw r, long long) const { return r; }
   const float* floats() const { return x; }            // host side: the plain float32 array
 };
@@ -62,6 +66,7 @@ struct SrcU8 {                        // uint8 frame ring [slots][H*W*Cin]; imag
     return slot >= 0 && slot < slots ? (long long)((size_t)slot * img) : -1;
   }
   __device__ __forceinline__ Raw load(long long base, size_t e) const { return *(const uint32_t*)(ring + (base < 0 ? 0 : base) + e); }
+  __device__ __forceinline__ Raw load_stream(long long base, size_t e) const { return load(base, e); }
   __device__ __forceinline__ f32x4 value(Raw v, long long base) const {
     const float sc = base < 0 ? 0.f : scale;
     return f32x4{(float)(v & 255u) * sc, (float)((v >> 8) & 255u) * sc, (float)((v >> 16) & 255u) * sc, (float)(v >> 24) * sc};
@@ -354,6 +359,118 @@ __global__ __launch_bounds__(256) void conv_fwd_c4_kernel(const ConvG g, const S
         *(f32x4*)(yn + (size_t)(16 * t + j) * g.Cout + n0) = v;
       }
     }
+  }
+}
+
+// The same layer type as a stream: a few persistent workgroups per compute unit walk (image, band of output rows)
+// items; the input rows of the NEXT item travel memory -> registers (whole lines, consecutive lanes 16 bytes apart)
+// while the patches of the current one are gathered from LDS and multiplied, so a compute unit always has several
+// bands' worth of loads in flight and the memory system sees nothing but full-line sequential reads.  (The patch
+// gather straight from memory reads 16 bytes per lane from lines 16 * stride bytes apart: a quarter of every 64-byte
+// line at stride 4, and the doom head's first layer ran at half the memory rate because of it.)  The layer's weight
+// fragments, every lane's tap offsets and the band geometry stay in registers for the whole kernel; a wave takes the
+// tiles wave, wave + NW, ... of a band (NW = 5 where a band has a multiple of five tiles).
+//   STG: input pixels of a band per thread (a band has at most STG * NW * 64 input pixels)
+// Measured on the doom head's first layer (4096 frames of 84x84x4, one MI355X): 110 -> 104 us from float32 frames, 93 ->
+// 86 us from the uint8 ring.  Counters on the float32 run: matrix pipe 39 % busy, other vector instructions 17 %, 43 % of
+// the wave cycles waiting -- the memory system delivers 4.9 TB/s of frames in and feature maps out to this stream.
+// Two bands in flight per workgroup (registers: three workgroups per compute unit instead of four) ran at 128 us,
+// nontemporal result stores changed nothing; the frames are fetched as nontemporal loads (108 -> 104 us).
+// Products and their order are those of conv_fwd_c4_kernel and conv_fwd_static_kernel: one accumulator per tile,
+// k-groups ascending.
+template <int NT, int NG, int NW, int STG, class S>
+__global__ __launch_bounds__(NW * 64) void conv_fwd_band_kernel(const ConvG g, const S src, const float* __restrict__ wfrag,
+                                                                 float* __restrict__ y, int items, int band_h, FastDiv dnb,
+                                                                 int nbands, int act_elu) {
+  extern __shared__ __attribute__((aligned(16))) float X[];      // [band rows * W][4]
+  constexpr int NTHR = NW * 64;
+  const int lane = threadIdx.x & 63, wave = wave_id(), q = lane >> 4, j = lane & 15;
+  f32x4 w[NG][NT];
+  int toff[NG];
+#pragma unroll
+  for (int gi = 0; gi < NG; ++gi) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) w[gi][t] = *(const f32x4*)(wfrag + (gi * NT + t) * 256 + lane * 4);
+    const int tap = 4 * gi + q;                             // this lane's quad of the group: one tap's four channels
+    const bool data = 4 * tap < g.K;
+    const int ky = data ? tap / g.k : 0, kx = data ? tap - ky * g.k : 0;
+    toff[gi] = (ky * g.W + kx) * 4;
+  }
+  // only the last group can hold the bias row's constant 1 (patch element K) and the zeros after it
+  const int kl = 4 * (4 * (NG - 1) + q);
+  const bool last_data = kl < g.K;
+  const float last_one = kl == g.K ? 1.f : 0.f;
+
+  using Raw = typename S::Raw;
+  struct Item { long long base; int n, oy0, oh, nin; };
+  auto locate_item = [&](int item) {
+    Item it;
+    it.n = fdiv(item, dnb);
+    it.oy0 = (item - it.n * nbands) * band_h;
+    it.oh = min(band_h, g.Ho - it.oy0);
+    it.nin = ((it.oh - 1) * g.s + g.k) * g.W;
+    it.base = src.image(it.n);
+    return it;
+  };
+  auto prefetch = [&](const Item& it, Raw (&raw)[STG]) {
+    const int in0 = (g.s * it.oy0) * g.W;
+#pragma unroll
+    for (int u = 0; u < STG; ++u) raw[u] = src.load_stream(it.base, (size_t)4 * (in0 + min((int)threadIdx.x + NTHR * u, it.nin - 1)));
+  };
+  int item = blockIdx.x;
+  if (item >= items) return;
+  Item cur = locate_item(item);
+  Raw raw[STG];
+  prefetch(cur, raw);
+  for (;;) {
+    // the next item is located before this one is staged (a ring slot comes from the index array: that read is then
+    // long back when the fetch addresses need it); always located and fetched from, the last one again at the end:
+    // no branch around loads
+    const int next = item + gridDim.x;
+    const bool more = next < items;                          // uniform
+    const Item nxt = locate_item(min(next, items - 1));
+#pragma unroll
+    for (int u = 0; u < STG; ++u) {
+      const int i = threadIdx.x + NTHR * u;
+      if (i < cur.nin) *(f32x4*)(X + 4 * i) = src.value(raw[u], cur.base);
+    }
+    lds_barrier();
+    prefetch(nxt, raw);
+    __builtin_amdgcn_sched_barrier(0);                       // the next band's loads go out before this band's products
+    const int npix = cur.oh * g.Wo;
+    float* yn = y + ((size_t)cur.n * g.Ho * g.Wo + (size_t)cur.oy0 * g.Wo) * g.Cout;
+    for (int t = wave; t < (npix + 15) / 16; t += NW) {
+      const int p = min(16 * t + j, npix - 1), oy = fdiv(p, g.dWo), ox = p - oy * g.Wo;
+      const float* xp = X + ((g.s * oy) * g.W + g.s * ox) * 4;
+      f32x4 b[NG];
+#pragma unroll
+      for (int gi = 0; gi < NG; ++gi) b[gi] = *(const f32x4*)(xp + toff[gi]);
+      b[NG - 1] = last_data ? b[NG - 1] : f32x4{last_one, 0.f, 0.f, 0.f};
+      f32x4 acc[NT];
+#pragma unroll
+      for (int i = 0; i < NT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int gi = 0; gi < NG; ++gi) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+#pragma unroll
+          for (int i = 0; i < NT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[gi][i][m], b[gi][m], acc[i], 0, 0, 0);
+        }
+      }
+      if (16 * t + j < npix) {
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+          const int n0 = 16 * i + q * 4;
+          if (n0 >= g.Cout) continue;
+          f32x4 v = acc[i];
+          if (act_elu) v = f32x4{elu_f(v[0]), elu_f(v[1]), elu_f(v[2]), elu_f(v[3])};
+          *(f32x4*)(yn + (size_t)(16 * t + j) * g.Cout + n0) = v;
+        }
+      }
+    }
+    if (!more) break;
+    lds_barrier();                                           // every wave has read its patches: the band may be replaced
+    item = next; cur = nxt;
   }
 }
 
@@ -1191,11 +1308,59 @@ inline int dx_layout(const ConvG& g, DxOff* offs) {
 
 inline int launched() { return (int)hipGetLastError(); }
 
+// Bands for conv_fwd_band_kernel: output rows per band and waves per workgroup such that little is wasted -- wave slots
+// (a band's 16-pixel tiles are dealt to nw waves), pixel columns of the last tile of a band, and input rows staged twice
+// because neighbouring bands overlap by k - s rows.  A band's input rows take at most 32 KB of LDS (four or five
+// workgroups per compute unit) and at most 6 pixels per thread.
+struct BandPlan { int band_h, nw, stg; };
+inline bool plan_bands(const ConvG& g, BandPlan& best) {
+  double best_score = 0.0;
+  for (int nw = 4; nw <= 5; ++nw)
+    for (int h = 1; h <= g.Ho; ++h) {
+      const int nin = ((h - 1) * g.s + g.k) * g.W, stg = cdiv(nin, nw * 64);
+      if ((size_t)nin * 16 > 32 * 1024 || stg > 6) break;
+      long long slots = 0, rows = 0;
+      for (int oy0 = 0; oy0 < g.Ho; oy0 += h) {
+        const int oh = std::min(h, g.Ho - oy0);
+        slots += (long long)nw * cdiv(cdiv(oh * g.Wo, 16), nw) * 16;
+        rows += (oh - 1) * g.s + g.k;
+      }
+      const double score = (double)(g.Ho * g.Wo) / (double)slots * std::min(1.0, (double)((g.Ho - 1) * g.s + g.k) / (double)rows);
+      if (score >= best_score) { best_score = score; best = BandPlan{h, nw, stg}; }
+    }
+  return best_score > 0.0;
+}
+
+template <int NT, int NG, int NW, int STG, class S>
+int launch_band(const ConvG& g, const S& src, const float* wfrag, float* y, int n_images, int band_h, int act_elu, hipStream_t st) {
+  const int nbands = cdiv(g.Ho, band_h);
+  const long long items = (long long)n_images * nbands;
+  if (items > 0x7fffffffll) return RLGAN_E_ALIGN;
+  const size_t lds = (size_t)((band_h - 1) * g.s + g.k) * g.W * 16;
+  // workgroups per compute unit: what the kernel's registers and the bands in LDS allow
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)conv_fwd_band_kernel<NT, NG, NW, STG, S>, NW * 64, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+  const int grid = (int)std::min<long long>(items, 256ll * per_cu);
+  hipLaunchKernelGGL((conv_fwd_band_kernel<NT, NG, NW, STG, S>), dim3(grid), dim3(NW * 64), lds, st, g, src, wfrag, y, (int)items, band_h,
+                     make_div(nbands), nbands, act_elu);
+  return (int)hipGetLastError();
+}
+
 template <class S>
 int launch_fwd(const ConvG& g, const S& src, const float* wfrag, float* y, int n_images, int act_elu, void* stream) {
   const long long Ml = (long long)n_images * g.Ho * g.Wo;
   if (Ml > 0x7fffffffll || ((uintptr_t)y & 15)) return RLGAN_E_ALIGN;
   const int M = (int)Ml;
+  BandPlan bp;
+  if (g.Cin == 4 && !((uintptr_t)wfrag & 15) && ((g.NG == 7 && g.NT == 1) || (g.NG == 3 && g.NT == 2)) && plan_bands(g, bp)) {
+    // a first layer as a stream of bands: the 5x5 layer of the doom head, the 3x3 layers of the universe heads
+    hipStream_t st = (hipStream_t)stream;
+#define RLGAN_FB(NTV, NGV, NWV, STGV) \
+    if (g.NT == NTV && g.NG == NGV && bp.nw == NWV && bp.stg <= STGV) return launch_band<NTV, NGV, NWV, STGV, S>(g, src, wfrag, y, n_images, bp.band_h, act_elu, st);
+    RLGAN_FB(1, 7, 4, 6) RLGAN_FB(1, 7, 5, 6)
+    RLGAN_FB(2, 3, 4, 3) RLGAN_FB(2, 3, 4, 6) RLGAN_FB(2, 3, 5, 3) RLGAN_FB(2, 3, 5, 6)
+#undef RLGAN_FB
+  }
   if (g.Cin == 4 && g.NG <= 3 && g.NT <= 2 && !((uintptr_t)wfrag & 15)) {      // 3x3 kernels; the 5x5 stride-4 layer measured no faster this way (128 against 122 us)
     // a first layer: one band of one image per workgroup, staged in LDS.  The band: as many output rows as 48 KB of
     // input rows allow (a 42x42 frame is one band, an 84x84 frame three or four); a clamped staging address must stay
