@@ -420,13 +420,15 @@ int rlgan_conv_backward_weights(const rlgan_conv_t* conv, const float* x, const 
  *   backward_weights: gwb[k+1, n] = [x 1]^T * dz    (kernel gradient, then the bias gradient row)
  * The sum over the long dimension can be cut into n_slabs ranges (more workgroups when the output alone
  * has few tiles); the partial products then go to `slabs`, device scratch of n_slabs * rows * n floats
- * (rows = m forward, k+1 for the weights), and are added in slab order, so the result does not depend
- * on timing.  n_slabs <= 1: no scratch.  rlgan_dense_slabs suggests a count for a product with an
+ * (rows = m forward, k+1 for the weights; m * k floats per slab for the input gradient's _split form),
+ * and are added in slab order, so the result does not depend on timing.  n_slabs <= 1: no scratch.  rlgan_dense_slabs suggests a count for a product with an
  * m_out x n_out result and k_red terms per element. */
 int rlgan_dense_slabs(int m_out, int n_out, int k_red);
 int rlgan_dense_forward(const float* x, int ldx, const float* wb, float* y, int ldy, int m, int k, int n, int act,
                         float* slabs, int n_slabs, void* stream);
 int rlgan_dense_backward_input(const float* dz, int lddz, const float* wb, float* dx, int lddx, int m, int k, int n, void* stream);
+int rlgan_dense_backward_input_split(const float* dz, int lddz, const float* wb, float* dx, int lddx, int m, int k, int n,
+                                     float* slabs, int n_slabs, void* stream);
 int rlgan_dense_backward_weights(const float* x, int ldx, const float* dz, int lddz, float* gwb, int m, int k, int n,
                                  float* slabs, int n_slabs, void* stream);
 

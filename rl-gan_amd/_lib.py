@@ -227,6 +227,7 @@ PROTOTYPES = {
     "rlgan_dense_slabs": [_i, _i, _i],
     "rlgan_dense_forward": [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp],
     "rlgan_dense_backward_input": [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp],
+    "rlgan_dense_backward_input_split": [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp],
     "rlgan_dense_backward_weights": [_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _i, _vp],
 }
 

@@ -265,12 +265,13 @@ class DenseLayer:
         self.grad = torch.zeros(self.n_params, dtype=torch.float32, device=device())
         self._scratch: Optional[torch.Tensor] = None
 
-    def _slabs(self, m_out: int, k_red: int):
-        """(scratch, count) for a product with an m_out x n result summed over k_red terms."""
-        ns = lib.rlgan_dense_slabs(m_out, self.n, k_red)
+    def _slabs(self, m_out: int, k_red: int, n_out: Optional[int] = None):
+        """(scratch, count) for a product with an m_out x n_out (default n) result summed over k_red terms."""
+        n_out = self.n if n_out is None else n_out
+        ns = lib.rlgan_dense_slabs(m_out, n_out, k_red)
         if ns <= 1:
             return None, 1
-        need = ns * m_out * self.n
+        need = ns * m_out * n_out
         if self._scratch is None or self._scratch.numel() < need:
             self._scratch = torch.empty(need, dtype=torch.float32, device=device())
         return self._scratch, ns
@@ -313,8 +314,9 @@ class DenseLayer:
         if not need_dx:
             return None
         dx = torch.empty_like(x)
-        check(lib.rlgan_dense_backward_input(dz.data_ptr(), self.n, self.canon.data_ptr(), dx.data_ptr(), self.k, m, self.k, self.n,
-                                             _stream()), "rlgan_dense_backward_input")
+        sc, ns = self._slabs(m, self.n, self.k)
+        check(lib.rlgan_dense_backward_input_split(dz.data_ptr(), self.n, self.canon.data_ptr(), dx.data_ptr(), self.k, m, self.k, self.n,
+                                                   None if sc is None else sc.data_ptr(), ns, _stream()), "rlgan_dense_backward_input_split")
         return dx
 
 

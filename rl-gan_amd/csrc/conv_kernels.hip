@@ -1593,9 +1593,12 @@ int rlgan_conv_backward_input(const rlgan_conv_t* conv, const float* dz, const f
     const int ntc = cdiv(g.Cin, 16);
     const size_t zimg = (size_t)g.Ho * g.Wo * (g.Cout + 4) * sizeof(float), tabs = (size_t)2 * g.s * g.s * std::max(1, offs.max_ng) * 4 * sizeof(int);
     // images per workgroup: a class's kernel fragments are fetched once per workgroup, so several small images share them
-    const int ipw = (int)std::max<size_t>(1, std::min<size_t>(8, (48 * 1024 - tabs) / zimg));
+    // (with few images, fewer per workgroup: at a batch of 32 four images each left eight workgroups for the whole chip)
+    int ipw = (int)std::max<size_t>(1, std::min<size_t>(8, (48 * 1024 - tabs) / zimg));
+    while (ipw > 1 && cdiv(n_images, ipw) < 512) --ipw;
     const size_t ilds = ipw * zimg + tabs;
-    if (ntc <= 2 && offs.max_ng * ntc <= DXI_MAXF && ilds <= 64 * 1024 && !(((uintptr_t)dx | (uintptr_t)dz | (uintptr_t)y_elu) & 15)) {
+    const bool few = n_images < 64;     // not even a workgroup per four compute units: the per-pixel-group kernel below spreads wider
+    if (!few && ntc <= 2 && offs.max_ng * ntc <= DXI_MAXF && ilds <= 64 * 1024 && !(((uintptr_t)dx | (uintptr_t)dz | (uintptr_t)y_elu) & 15)) {
       // pixels no class covers (stride beyond the kernel) keep the zeros of the other kernel's classes: every class
       // with taps writes all of its pixels, a class without taps (NG == 0) must still be cleared
       bool all_have_taps = true;

@@ -304,7 +304,10 @@ __global__ __launch_bounds__(256) void deconv_few_fwd_kernel(const float* __rest
   ws.set(wff, c * T::KG);
   const float bj = bias[16 * c + j];
   const float* xa = lds + j * T::XS + 4 * q;
-  for (int ph = 0; ph < 4; ++ph) {
+  // one stride phase per workgroup (blockIdx.y): four times the workgroups -- at a batch of 32 the layer is two image
+  // tiles, and with all four phases in one workgroup it took 108 us at any batch size (a chain of 4608 products per wave)
+  {
+    const int ph = blockIdx.y;
     const int ry = ph >> 1, rx = ph & 1;
     f32x4 acc[T::GA * T::GA];
 #pragma unroll
@@ -645,7 +648,7 @@ int rlgan_deconv_fused_forward(const rlgan_deconv_t* d, const float* x, const fl
                        x, wff, bias, y, n_images, act_relu);
   } else if (kind == FUSED_FEW_FWD) {
     allow_lds(deconv_few_fwd_kernel<Few>, Few::FWD_LDS);
-    hipLaunchKernelGGL(deconv_few_fwd_kernel<Few>, dim3(cdiv(n_images, 16)), dim3(256), Few::FWD_LDS, (hipStream_t)stream,
+    hipLaunchKernelGGL(deconv_few_fwd_kernel<Few>, dim3(cdiv(n_images, 16), 4), dim3(256), Few::FWD_LDS, (hipStream_t)stream,
                        x, wff, bias, y, n_images, act_relu);
   } else {
     allow_lds(deconv_narrow_fwd_kernel<Last>, Last::FWD_LDS);

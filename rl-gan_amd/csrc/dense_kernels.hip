@@ -106,7 +106,10 @@ __device__ __forceinline__ void tile_store(float* t, const f32x4 (&r)[2]) {
 }
 
 // C tile of one workgroup: four waves, 32 x 32 each (2 x 2 MFMA tiles); the next reduction step's
-// operands travel global -> registers while the current one is multiplied out of LDS.
+// operands travel global -> registers while the current one is multiplied out of LDS.  (Two or three steps in
+// flight through further register sets: 1 to 2 % slower at batch 4096 and no faster at batch 32, where a product with
+// few output tiles is a chain of memory round trips per workgroup -- what helps there is cutting the reduction into
+// slabs, which every product can now ask for.)
 template <bool A_KCONT, bool B_KCONT>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
   __shared__ __attribute__((aligned(16))) float lds[4 * TILE_FLOATS];   // A and B tiles, two stages
@@ -272,7 +275,11 @@ int rlgan_dense_slabs(int m_out, int n_out, int k_red) {
   if (m_out <= 0 || n_out <= 0 || k_red <= 0) return RLGAN_E_ARG;
   const long long tiles = (long long)cdiv(m_out, BM) * cdiv(n_out, BN);
   const int by_chip = (int)std::min<long long>(256, cdiv(1024, tiles));       // about four workgroups per compute unit
-  const int by_work = std::max(1, k_red / (4 * BK));                          // at least four reduction steps each
+  // at least four reduction steps each; two when the result is a single row tile high (a batch of 32 or 64: every
+  // product is then a few workgroups walking a chain of memory round trips; the pixel iteration at batch 32 ran 6 %
+  // faster).  Results for the batch sizes above that are cut as before, so a row's result is the same bits at 512 and
+  // at 4096 rows.
+  const int by_work = std::max(1, k_red / ((m_out <= BM ? 2 : 4) * BK));
   return std::max(1, std::min(by_chip, by_work));
 }
 
@@ -283,11 +290,15 @@ int rlgan_dense_forward(const float* x, int ldx, const float* wb, float* y, int 
   return launch_gemm<true, false>(g, slabs, n_slabs, stream);
 }
 
-int rlgan_dense_backward_input(const float* dz, int lddz, const float* wb, float* dx, int lddx, int m, int k, int n, void* stream) {
+int rlgan_dense_backward_input_split(const float* dz, int lddz, const float* wb, float* dx, int lddx, int m, int k, int n,
+                                     float* slabs, int n_slabs, void* stream) {
   if (lddz < n || lddx < k) return RLGAN_E_ARG;
   // B[kk = hidden unit][x = input feature] = Wb[x][kk]: rows of Wb are the x, kk is contiguous
   GemmArgs g{dz, wb, dx, lddz, n, lddx, m, k, n, m, n, /*b_x*/ k, /*b_k*/ n, -1, -1, 0, 0, 0};
-  return launch_gemm<true, true>(g, nullptr, 1, stream);
+  return launch_gemm<true, true>(g, slabs, n_slabs, stream);
+}
+int rlgan_dense_backward_input(const float* dz, int lddz, const float* wb, float* dx, int lddx, int m, int k, int n, void* stream) {
+  return rlgan_dense_backward_input_split(dz, lddz, wb, dx, lddx, m, k, n, nullptr, 1, stream);
 }
 
 int rlgan_dense_backward_weights(const float* x, int ldx, const float* dz, int lddz, float* gwb, int m, int k, int n,

@@ -144,8 +144,10 @@ class DeconvLayer:
         if not need_dx:
             return None
         dx = torch.empty_like(x)
-        check(lib.rlgan_dense_backward_input(dcols.data_ptr(), self.kk, self.wmat.data_ptr(), dx.data_ptr(), self.c_in, rows, self.c_in,
-                                             self.kk, _stream()), "rlgan_dense_backward_input")
+        sc, ns = self._slabs(rows, self.c_in, self.kk)
+        check(lib.rlgan_dense_backward_input_split(dcols.data_ptr(), self.kk, self.wmat.data_ptr(), dx.data_ptr(), self.c_in, rows, self.c_in,
+                                                   self.kk, None if sc is None else sc.data_ptr(), ns, _stream()),
+              "rlgan_dense_backward_input_split")
         return dx
 
 

@@ -86,8 +86,10 @@ class _Net:
                       "rlgan_act_backward")
                 d = dz
             dx = torch.empty_like(acts_[i])
-            check(lib.rlgan_dense_backward_input(d.data_ptr(), L.n, L.canon.data_ptr(), dx.data_ptr(), L.k, d.shape[0], L.k, L.n, _stream()),
-                  "rlgan_dense_backward_input")
+            sc, ns = L._slabs(d.shape[0], L.n, L.k)
+            check(lib.rlgan_dense_backward_input_split(d.data_ptr(), L.n, L.canon.data_ptr(), dx.data_ptr(), L.k, d.shape[0], L.k, L.n,
+                                                       None if sc is None else sc.data_ptr(), ns, _stream()),
+                  "rlgan_dense_backward_input_split")
             d = dx
         return d
 

@@ -74,6 +74,33 @@ def test_dense_head_forward_and_backward(m, k, n):
     close(zt.cpu().numpy(), x @ w + b, what="dense linear")
 
 
+@pytest.mark.parametrize("m,k,n,ns", [(32, 200, 1152, 9), (288, 128, 1024, 8), (5, 20, 12, 3)])
+def test_dense_input_gradient_in_slabs(m, k, n, ns):
+    """dX = dZ * W^T with the sum over the n hidden units cut into slabs (the batch-32 shapes of the pixel generator's
+    decoder, where the output alone has a handful of tiles): equal to the float64 product, and the same bits on a second
+    call (slabs are added in slab order)."""
+    from rl_gan_amd import _lib
+    from gpu_util import close
+    rng = np.random.RandomState(m + n)
+    dz = rng.standard_normal((m, n)).astype(np.float32)
+    w = (rng.uniform(-1, 1, (k, n)) * np.sqrt(6.0 / (k + n))).astype(np.float32)
+    wb = torch.from_numpy(np.concatenate([w.ravel(), np.zeros(n, np.float32)])).cuda()
+    dzt = torch.from_numpy(dz).cuda()
+    slabs = torch.empty(ns * m * k, device="cuda")
+    outs = []
+    for _ in range(2):
+        dx = torch.full((m, k), float("nan"), device="cuda")
+        assert _lib.lib.rlgan_dense_backward_input_split(dzt.data_ptr(), n, wb.data_ptr(), dx.data_ptr(), k, m, k, n,
+                                                         slabs.data_ptr(), ns, None) == 0
+        outs.append(dx.cpu().numpy())
+    close(outs[0], dz.astype(np.float64) @ w.astype(np.float64).T, what="dX in slabs")
+    np.testing.assert_array_equal(outs[0], outs[1])
+    one = torch.empty((m, k), device="cuda")
+    assert _lib.lib.rlgan_dense_backward_input(dzt.data_ptr(), n, wb.data_ptr(), one.data_ptr(), k, m, k, n, None) == 0
+    close(one.cpu().numpy(), outs[0].astype(np.float64), what="one slab against several")
+    assert _lib.lib.rlgan_dense_backward_input_split(dzt.data_ptr(), n, wb.data_ptr(), one.data_ptr(), k, m, k, n, None, 4, None) == -1
+
+
 def test_encoder_with_dense_head_end_to_end():
     """doom head + fc(256): features, and the gradient reaching the first conv layer."""
     import rl_gan_amd as R

@@ -30,13 +30,14 @@ def wrap(fname, dims):
     setattr(_lib.lib, fname, f)
 
 
-build = dict(workloads.WORKLOADS)[name]
+entry = [w for w in workloads.WORKLOADS if w[0] == name][0]
+build, batch = entry[1], entry[2] or 4096
 if name.startswith("pixel"):
     # the graph would hide the calls: build the trainer by hand the way the workload does, without capture
     import types
     orig = R.PixelGanTrainer.capture
     R.PixelGanTrainer.capture = lambda self: None
-step = build(4096)
+step = build(batch)
 for _ in range(3):
     step()
 torch.cuda.synchronize()
