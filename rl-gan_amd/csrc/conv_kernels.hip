@@ -1352,7 +1352,10 @@ int launch_fwd(const ConvG& g, const S& src, const float* wfrag, float* y, int n
   if (Ml > 0x7fffffffll || ((uintptr_t)y & 15)) return RLGAN_E_ALIGN;
   const int M = (int)Ml;
   BandPlan bp;
-  if (g.Cin == 4 && !((uintptr_t)wfrag & 15) && ((g.NG == 7 && g.NT == 1) || (g.NG == 3 && g.NT == 2)) && plan_bands(g, bp)) {
+  // (a 3x3 layer on uint8 frames that fit LDS whole -- 42x42x4 -- stays with the one-image-per-workgroup kernel below:
+  // 62 against 64 us for 4096 frames, 118 against 127 us inside the pixel iteration)
+  const bool small_u8 = !src.floats() && (size_t)g.H * g.W * 16 <= 48 * 1024 && g.NG <= 3;
+  if (g.Cin == 4 && !small_u8 && !((uintptr_t)wfrag & 15) && ((g.NG == 7 && g.NT == 1) || (g.NG == 3 && g.NT == 2)) && plan_bands(g, bp)) {
     // a first layer as a stream of bands: the 5x5 layer of the doom head, the 3x3 layers of the universe heads
     hipStream_t st = (hipStream_t)stream;
 #define RLGAN_FB(NTV, NGV, NWV, STGV) \
