@@ -195,6 +195,36 @@ def test_weight_gradient_two_ways(h, cin, cout, k, st, n):
         assert torch.equal(L.grad, got[ns])
 
 
+@pytest.mark.parametrize("name", ["doom", "universe"])
+def test_first_layer_streamed_in_bands(name):
+    """The first layer of the 84x84x4 encoders (5x5 stride 4 -> 8 channels, Conv_model.py:15-16; 3x3 stride 2 -> 32
+    channels, Conv_model.py:38-39) walks (image, band of output rows) items with persistent workgroups.  300 images are
+    more items than workgroups, batches of 7 fewer: both give the same bits per image, from float32 frames and from the
+    uint8 ring through an index array (slots out of range read as zero images), and the float64 restatement's values."""
+    import rl_gan_amd as R
+    from gpu_util import close
+    from oracle import conv as oc
+    f, k, st = (8, 5, 4) if name == "doom" else (32, 3, 2)
+    n = 300
+    L = R.ConvLayer(84, 84, 4, f, k, st, rng=np.random.RandomState(7), bias_init=0.01)
+    g = torch.Generator(device="cuda").manual_seed(2)
+    ring = torch.randint(0, 256, (n + 2, 84 * 84 * 4), dtype=torch.uint8, device="cuda", generator=g)
+    idx = torch.randperm(n + 2, device="cuda", generator=g)[:n].contiguous()
+    idx[5], idx[n - 1] = -1, n + 9                                   # no such slots
+    ok = ((idx >= 0) & (idx < n + 2)).to(torch.float32).reshape(n, 1)
+    x = (ring[idx.clamp(0, n + 1)].to(torch.float32) * torch.tensor(np.float32(1.0 / 255), device="cuda") * ok).reshape(n, 84, 84, 4).contiguous()
+    y = L.forward(x)
+    for i in range(0, n, 7 * 6):
+        assert torch.equal(L.forward(x[i:i + 7].contiguous()), y[i:i + 7])
+    assert torch.equal(L.forward_frames(R.FrameRef(ring, idx, 1.0 / 255)), y)
+    w, b = L.kernel_bias()
+    yo, _ = oc.conv_forward(x[3:7].cpu().numpy().astype(np.float64), w.astype(np.float64), b.astype(np.float64), k, st)
+    close(y[3:7].cpu().numpy(), yo, what=f"{name} first layer")
+    z = L.forward(x[:4].contiguous(), act=False)
+    zo, _ = oc.conv_forward(x[:4].cpu().numpy().astype(np.float64), w.astype(np.float64), b.astype(np.float64), k, st, act=False)
+    close(z.cpu().numpy(), zo, what=f"{name} first layer, linear")
+
+
 @pytest.mark.parametrize("hw,n", [(42, 7), (12, 3)])
 def test_single_frame_first_layer_on_2x2_blocks(hw, n):
     """One-channel frames (the single-frame encoder, Curious_GAN_mario.py:313-314): the 3x3 stride-2 first layer runs as a
