@@ -1337,9 +1337,13 @@ int launch_band(const ConvG& g, const S& src, const float* wfrag, float* y, int 
   const long long items = (long long)n_images * nbands;
   if (items > 0x7fffffffll) return RLGAN_E_ALIGN;
   const size_t lds = (size_t)((band_h - 1) * g.s + g.k) * g.W * 16;
-  // workgroups per compute unit: what the kernel's registers and the bands in LDS allow
-  int per_cu = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)conv_fwd_band_kernel<NT, NG, NW, STG, S>, NW * 64, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+  // workgroups per compute unit: what the kernel's registers and the bands in LDS allow (asked once per band size)
+  static size_t asked_lds = 0;
+  static int per_cu = 0;
+  if (per_cu == 0 || asked_lds != lds) {
+    asked_lds = lds;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)conv_fwd_band_kernel<NT, NG, NW, STG, S>, NW * 64, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+  }
   const int grid = (int)std::min<long long>(items, 256ll * per_cu);
   hipLaunchKernelGGL((conv_fwd_band_kernel<NT, NG, NW, STG, S>), dim3(grid), dim3(NW * 64), lds, st, g, src, wfrag, y, (int)items, band_h,
                      make_div(nbands), nbands, act_elu);
@@ -1355,7 +1359,7 @@ int launch_fwd(const ConvG& g, const S& src, const float* wfrag, float* y, int n
   // (a 3x3 layer on uint8 frames that fit LDS whole -- 42x42x4 -- stays with the one-image-per-workgroup kernel below:
   // 62 against 64 us for 4096 frames, 118 against 127 us inside the pixel iteration)
   const bool small_u8 = !src.floats() && (size_t)g.H * g.W * 16 <= 48 * 1024 && g.NG <= 3;
-  if (g.Cin == 4 && !small_u8 && !((uintptr_t)wfrag & 15) && ((g.NG == 7 && g.NT == 1) || (g.NG == 3 && g.NT == 2)) && plan_bands(g, bp)) {
+  if (g.Cin == 4 && !small_u8 && !(((uintptr_t)wfrag | (uintptr_t)src.floats()) & 15) && ((g.NG == 7 && g.NT == 1) || (g.NG == 3 && g.NT == 2)) && plan_bands(g, bp)) {
     // a first layer as a stream of bands: the 5x5 layer of the doom head, the 3x3 layers of the universe heads
     hipStream_t st = (hipStream_t)stream;
 #define RLGAN_FB(NTV, NGV, NWV, STGV) \
