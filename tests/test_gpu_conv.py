@@ -159,6 +159,32 @@ def test_input_gradient_two_ways(h, cin, cout, k, st):
     close(a.cpu().numpy(), b.cpu().numpy().astype(np.float64), what="dX mfma vs gather")
 
 
+@pytest.mark.parametrize("n", [3, 70, 600])
+def test_input_gradient_of_the_3x3_layer_at_any_batch(n):
+    """dX of the 32 -> 32 channel 3x3 stride-2 layer on 20x20 maps (Conv_model.py:38-44) takes the per-pixel-group kernel
+    below 64 images and the image-in-LDS kernel above, with one to four images per workgroup depending on how many
+    workgroups that leaves: every form against the float64 restatement, and an image's gradient does not depend on the
+    batch it came in beyond the kernel choice (rows 0..2 of the 70- and 600-image batches are the same bits)."""
+    import rl_gan_amd as R
+    from gpu_util import close
+    from oracle import conv as oc
+    rng = np.random.RandomState(5)
+    L = R.ConvLayer(20, 20, 32, 32, 3, 2, rng=rng, bias_init=0.01)
+    g = torch.Generator(device="cuda").manual_seed(4)
+    x = torch.rand(600, 20, 20, 32, device="cuda", generator=g)[:n].contiguous()
+    y = L.forward(x)
+    dy = torch.randn(600, *y.shape[1:], device="cuda", generator=g)[:n].contiguous()
+    dx = L.backward(x, y, dy, need_dw=False)
+    w, b = L.kernel_bias()
+    m = min(n, 3)
+    _, cache = oc.conv_forward(x[:m].cpu().numpy().astype(np.float64), w.astype(np.float64), b.astype(np.float64), 3, 2)
+    dxo, _, _ = oc.conv_backward(dy[:m].cpu().numpy().astype(np.float64), w.astype(np.float64), cache, 3, 2)
+    close(dx[:m].cpu().numpy(), dxo, what=f"dX of the first images of {n}")
+    if n == 600:
+        d70 = L.backward(x[:70].contiguous(), y[:70].contiguous(), dy[:70].contiguous(), need_dw=False)
+        assert torch.equal(d70[:3], dx[:3])
+
+
 @pytest.mark.parametrize("h,cin,cout,k,st,n", [(84, 4, 8, 5, 4, 7), (42, 4, 32, 3, 2, 9), (20, 8, 16, 3, 2, 40), (42, 4, 32, 3, 2, 30),
                                                (21, 4, 16, 3, 2, 11), (21, 4, 32, 2, 1, 30)])
 def test_weight_gradient_two_ways(h, cin, cout, k, st, n):
