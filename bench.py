@@ -410,8 +410,16 @@ def main():
             L.engine.set_chains(2)
             L._graph = None
             L.capture()
-            dt2 = measure(args.steps)[0]
-            out["update_forms"] = {"fused_phases_ms_per_step": out["ms_per_step"], "two_chains_ms_per_step": round(dt2 / args.steps * 1e3, 4)}
+            dt2, dt2_min, dt2_max, rep2 = measure(args.steps)
+            forms = {"fused_phases_ms_per_step": out["ms_per_step"], "two_chains_ms_per_step": round(dt2 / args.steps * 1e3, 4)}
+            if dt2 < 0.99 * out["ms_per_step"] * 1e-3 * args.steps or os.environ.get("RLGAN_BENCH_REPORT_FORM") == "two_chains":   # (the variable: rehearsal of this branch on one GPU)
+                # both forms give the same bits (tests/test_gpu_dp.py); the line reports the one this machine's exchange
+                # latency favours, and says which
+                better = headline(dt2, dt2_min, dt2_max, rep2, launch)
+                better["config"]["update_form"] = "two_chains"
+                out.update({k: better[k] for k in ("value", "ms_per_step", "repeats", "ms_per_step_min", "ms_per_step_max",
+                                                   "env_steps_per_s", "config")})
+            out["update_forms"] = forms
         except Exception as e:
             print(f"[bench] two-chain form not timed ({type(e).__name__}: {e})", file=sys.stderr, flush=True)
             out["update_forms"] = f"two_chains failed: {type(e).__name__}"
