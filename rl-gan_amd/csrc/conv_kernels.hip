@@ -474,6 +474,138 @@ __global__ __launch_bounds__(NW * 64) void conv_fwd_band_kernel(const ConvG g, c
   }
 }
 
+// A first layer with EIGHT output channels (the doom head's 5x5 stride-4 layer, Conv_model.py:15-16) fills only half of
+// a 16-row matrix tile.  v_mfma_f32_4x4x1_16b_f32 multiplies sixteen independent 4x4 blocks per instruction, one patch
+// element at a time: block = (group of four pixels, four of the eight channels), so one instruction covers 32 pixels x
+// 8 channels with nothing wasted (8 cycles against the 2 x 32 of two half-empty 16x16x4 tiles; tools/mfma4x4_probe.hip:
+// 131-140 TFLOP/s with two accumulators).  Lane 4 * block + i supplies the weight of channel 4 * cg + i (row operand,
+// one register per patch element, held for the whole kernel) and patch element k of pixel i of the block's group (column
+// operand: the four channels of a tap are one ds_read_b128, four instructions); register r of lane 4 * block + j ends up
+// with channel 4 * cg + r of pixel j, i.e. four consecutive channels: one 16-byte store.  All lanes work on the same tap,
+// so tap offsets are instruction immediates.  The band of input rows sits in LDS with the pixels of a row de-interleaved
+// by x % 4 (CP pixels per class): the 32 pixels of a tile, 4 input pixels apart, are then consecutive 16-byte slots
+// (read in place they are 64 bytes apart: four-way bank conflicts), and CP % 8 = 6 keeps the staging stores of eight
+// consecutive pixels on eight different slots.  Streaming as in conv_fwd_band_kernel: persistent workgroups, the next
+// (image, band) item's rows memory -> registers while this one is multiplied.  The sum runs over the patch elements in
+// order on two accumulators taking turns (bias first), so the last bits differ from the 16x16x4 kernels'.
+template <int K, int CP, int NW, int STG, int DEPTH, class S>
+__global__ __launch_bounds__(NW * 64) void conv_fwd_c8_kernel(const ConvG g, const S src, const float* __restrict__ wfrag,
+                                                               float* __restrict__ y, int items, int band_h, FastDiv dnb,
+                                                               int nbands, int act_elu) {
+  extern __shared__ __attribute__((aligned(16))) float X[];      // [band rows][4 classes][CP pixels][4 channels]
+  constexpr int NTHR = NW * 64, NTAP = K * K, RP = 4 * CP * 4;   // RP: floats per staged row
+  const int lane = threadIdx.x & 63, wave = wave_id();
+  const int blk = lane >> 2, jj = lane & 3, pg = blk >> 1, cg = blk & 1;
+  float wk[NTAP][4];                                             // this lane's row operands: W[4 * tap + c][4 * cg + jj]
+#pragma unroll
+  for (int t = 0; t < NTAP; ++t) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) wk[t][c] = wfrag[frag_offset(1, 4 * t + c, 4 * cg + jj)];
+  }
+  f32x4 bias4;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) bias4[r] = wfrag[frag_offset(1, 4 * NTAP, 4 * cg + r)];
+  // where this thread's staged pixels go: band pixel (row, x) -> row * RP + ((x & 3) * CP + (x >> 2)) * 4
+  int wslot[STG];
+#pragma unroll
+  for (int u = 0; u < STG; ++u) {
+    const int i = threadIdx.x + NTHR * u, r = i / g.W, x = i - r * g.W;
+    wslot[u] = r * RP + ((x & 3) * CP + (x >> 2)) * 4;
+  }
+  using Raw = typename S::Raw;
+  struct Item { long long base; int n, oy0, oh, nin; };
+  auto locate_item = [&](int item) {
+    Item it;
+    it.n = fdiv(item, dnb);
+    it.oy0 = (item - it.n * nbands) * band_h;
+    it.oh = min(band_h, g.Ho - it.oy0);
+    it.nin = ((it.oh - 1) * 4 + K) * g.W;
+    it.base = src.image(it.n);
+    return it;
+  };
+  auto prefetch = [&](const Item& it, Raw (&raw)[STG]) {
+    const int in0 = (4 * it.oy0) * g.W;
+#pragma unroll
+    for (int u = 0; u < STG; ++u) raw[u] = src.load_stream(it.base, (size_t)4 * (in0 + min((int)threadIdx.x + NTHR * u, it.nin - 1)));
+  };
+  int round = 0;
+  auto compute = [&](const Item& cur) {
+    const int npix = cur.oh * g.Wo, ntiles = (npix + 31) >> 5;
+    float* yn = y + ((size_t)cur.n * g.Ho * g.Wo + (size_t)cur.oy0 * g.Wo) * 8;
+    // a band's tiles are dealt to the waves starting at a different wave every round, so that a band whose tiles do
+    // not deal evenly does not load the same SIMD every time
+    for (int t = (wave - round) & (NW - 1); t < ntiles; t += NW) {
+      const int p = min(32 * t + 4 * pg + jj, npix - 1), oy = fdiv(p, g.dWo), ox = p - oy * g.Wo;
+      const float* xp = X + (4 * oy) * RP + ox * 4;          // tap (ky, kx) is at xp + ky * RP + ((kx & 3) * CP + (kx >> 2)) * 4
+      f32x4 acc0 = bias4, acc1{0.f, 0.f, 0.f, 0.f};
+      f32x4 b[2][K];
+#pragma unroll
+      for (int kx = 0; kx < K; ++kx) b[0][kx] = *(const f32x4*)(xp + ((kx & 3) * CP + (kx >> 2)) * 4);
+#pragma unroll
+      for (int ky = 0; ky < K; ++ky) {
+        if (ky + 1 < K) {
+#pragma unroll
+          for (int kx = 0; kx < K; ++kx) b[(ky + 1) & 1][kx] = *(const f32x4*)(xp + (ky + 1) * RP + ((kx & 3) * CP + (kx >> 2)) * 4);
+        }
+        __builtin_amdgcn_sched_barrier(0);                   // the next kernel row's reads stay ahead of this row's products
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) {
+          const f32x4 bv = b[ky & 1][kx];
+          acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wk[ky * K + kx][0], bv[0], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wk[ky * K + kx][1], bv[1], acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wk[ky * K + kx][2], bv[2], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wk[ky * K + kx][3], bv[3], acc1, 0, 0, 0);
+        }
+      }
+      if (32 * t + 4 * pg + jj < npix) {
+        f32x4 v = acc0 + acc1;
+        if (act_elu) v = f32x4{elu_f(v[0]), elu_f(v[1]), elu_f(v[2]), elu_f(v[3])};
+        *(f32x4*)(yn + (size_t)(32 * t + 4 * pg + jj) * 8 + 4 * cg) = v;
+      }
+    }
+  };
+  // DEPTH items of input rows are in flight per workgroup.  An item is located (a ring slot comes from the index
+  // array) a whole item before its rows are requested; the last item is located and fetched again at the end rather
+  // than put a branch around loads.
+  int item = blockIdx.x;
+  if (item >= items) return;
+  const int grid = gridDim.x;
+  Item its[DEPTH];
+  Raw raw[DEPTH][STG];
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) {
+    its[d] = locate_item(min(item + d * grid, items - 1));
+    prefetch(its[d], raw[d]);
+  }
+  for (;;) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+      const Item nxt = locate_item(min(item + DEPTH * grid, items - 1));
+      const Item cur = its[d];
+#pragma unroll
+      for (int u = 0; u < STG; ++u) {
+        if ((int)threadIdx.x + NTHR * u < cur.nin) *(f32x4*)(X + wslot[u]) = src.value(raw[d][u], cur.base);
+      }
+      lds_barrier();
+      its[d] = nxt;
+      if constexpr (DEPTH == 1) {
+        prefetch(nxt, raw[d]);                               // the next band's loads go out before this band's products
+        __builtin_amdgcn_sched_barrier(0);
+        compute(cur);
+      } else {
+        // another band is in flight already; requests after the result stores, so that waiting for the OTHER band's
+        // rows (requested before them) never has to wait for these
+        compute(cur);
+        __builtin_amdgcn_sched_barrier(0);
+        prefetch(nxt, raw[d]);
+      }
+      item += grid; ++round;
+      if (item >= items) return;                             // uniform
+      lds_barrier();                                         // every wave has read its patches: the band may be replaced
+    }
+  }
+}
+
 // ---------------------------------------------------------------- dZ = dY * ELU'(Y)   (ELU' from the output: y > 0 ? 1 : y + 1)
 __global__ void elu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dz, size_t n) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1355,6 +1487,28 @@ int launch_fwd(const ConvG& g, const S& src, const float* wfrag, float* y, int n
   const long long Ml = (long long)n_images * g.Ho * g.Wo;
   if (Ml > 0x7fffffffll || ((uintptr_t)y & 15)) return RLGAN_E_ALIGN;
   const int M = (int)Ml;
+  if (g.Cin == 4 && g.Cout == 8 && g.k == 5 && g.s == 4 && g.W == 84 && g.Ho >= 4 && !(((uintptr_t)wfrag | (uintptr_t)src.floats()) & 15)) {
+    // the doom head's first layer on 84-pixel rows: full tiles of the sixteen-block matrix instruction
+    // bands of four output rows (17 input rows, 24 KB of LDS), two waves a workgroup, four workgroups per compute unit
+    // (the kernels hold 100 weight registers: two waves per SIMD); with eight-row bands and four waves: 102 against 96 us
+    constexpr int K = 5, CP = 22, NW = 2, STG = 12, BAND_H = 4;        // 1,428 pixels a band <= STG * NW * 64
+    // one item of rows in flight per workgroup: two or three (uint8 rows are few registers) ran 4 to 7 % slower
+    constexpr int DEPTH = 1;
+    const int nbands = cdiv(g.Ho, BAND_H);
+    const long long items = (long long)n_images * nbands;
+    if (items <= 0x7fffffffll) {
+      const size_t lds = (size_t)((BAND_H - 1) * 4 + K) * 4 * CP * 16;
+      static int per_cu = 0;
+      if (per_cu == 0) {
+        (void)hipFuncSetAttribute((const void*)conv_fwd_c8_kernel<K, CP, NW, STG, DEPTH, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)conv_fwd_c8_kernel<K, CP, NW, STG, DEPTH, S>, NW * 64, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+      }
+      const int grid = (int)std::min<long long>(items, 256ll * per_cu);
+      hipLaunchKernelGGL((conv_fwd_c8_kernel<K, CP, NW, STG, DEPTH, S>), dim3(grid), dim3(NW * 64), lds, (hipStream_t)stream, g, src, wfrag, y,
+                         (int)items, BAND_H, make_div(nbands), nbands, act_elu);
+      return launched();
+    }
+  }
   BandPlan bp;
   // (a 3x3 layer on uint8 frames that fit LDS whole -- 42x42x4 -- stays with the one-image-per-workgroup kernel below:
   // 62 against 64 us for 4096 frames, 118 against 127 us inside the pixel iteration)
