@@ -332,6 +332,34 @@ def test_one_batch_encoded_in_two_calls(c_in):
         assert torch.equal(L.grad, g)
 
 
+@pytest.mark.parametrize("h,cin,cout,n_few,n_many", [(4, 32, 64, 40, 17000), (4, 32, 32, 300, 16500), (9, 32, 32, 100, 1100)])
+def test_last_layers_with_few_tiles(h, cin, cout, n_few, n_many):
+    """A 3x3 stride-2 layer on a small map: with at most 16384 output pixels in the batch every wave takes one tile and
+    loads all it needs at once, above that the tiles are walked by resident workgroups.  Both against the float64
+    restatement, and an image's output is the same bits in either batch (same products in the same order)."""
+    import rl_gan_amd as R
+    from gpu_util import close
+    from oracle import conv as oc
+    rng = np.random.RandomState(h + cout)
+    spec = ((cout, 3, 2),)
+    params = [(w.astype(np.float32).astype(np.float64), b.astype(np.float32).astype(np.float64))
+              for w, b in oc.init_encoder(rng, spec, cin, bias=0.001)]
+    L = R.ConvLayer(h, h, cin, cout, 3, 2, kernel=params[0][0], bias=params[0][1])
+    assert n_few * L.h_out * L.w_out <= 16384 < n_many * L.h_out * L.w_out
+    x = rng.uniform(-1, 1, (n_many, h, h, cin)).astype(np.float32)
+    xt = torch.from_numpy(x).cuda()
+    many = L.forward(xt)
+    few = L.forward(xt[:n_few].contiguous())
+    assert torch.equal(few, many[:n_few])
+    y, _ = oc.encoder_forward(x[:n_few].astype(np.float64), params, spec)
+    close(few.cpu().numpy(), y, what="few tiles")
+    tail = slice(n_many - 5, n_many)
+    y, _ = oc.encoder_forward(x[tail].astype(np.float64), params, spec)
+    close(many[tail].cpu().numpy(), y, what="many tiles")
+    one = L.forward(xt[7:8].contiguous(), act=False)                        # a lone image, no activation
+    assert torch.equal(one, L.forward(xt[:n_few].contiguous(), act=False)[7:8])
+
+
 def test_elu_absolute_accuracy():
     """tf.nn.elu on the device is exp(z) - 1 through the hardware's exp2, the form TensorFlow's own kernel has: within
     1.5e-7 of the float64 value for every z (about an ulp of the exponential), over twelve decades of |z|."""

@@ -31,6 +31,31 @@ def timeit(fn):
     return a.elapsed_time(b) / REP * 1e3      # us
 
 
+def timeit_graph(fn, reps=20):
+    """Like timeit for kernels shorter than a launch from Python: `reps` calls recorded as one graph, the graph replayed."""
+    fn()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        fn()
+        side.synchronize()
+        with torch.cuda.graph(graph, stream=side):
+            for _ in range(reps):
+                fn()
+    torch.cuda.synchronize()
+    for _ in range(3):
+        graph.replay()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    a.record()
+    for _ in range(10):
+        graph.replay()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / (10 * reps) * 1e3      # us
+
+
 def main():
     cfg = R.LearnerConfig(n_env=B, batch_size=B, memory_capacity=max(1 << 16, 4 * B), seed=1)
     L = R.CuriousLearner(cfg)
