@@ -43,6 +43,7 @@ for _ in range(3):
 torch.cuda.synchronize()
 wrap("rlgan_dense_forward", (5, 6, 7))            # m, k, n
 wrap("rlgan_dense_backward_input", (5, 6, 7))
+wrap("rlgan_dense_backward_input_split", (5, 6, 7))
 wrap("rlgan_dense_backward_weights", (5, 6, 7))
 step()
 torch.cuda.synchronize()
