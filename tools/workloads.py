@@ -141,7 +141,7 @@ def conv_ddpg_doom(B=4096, a_dim=6, head=None):
     def body():
         # neither step trains the encoder (Conv_model.py:616,784), so the features of s serve both: two encoder passes per
         # update where the reference's two sess.run calls make three
-        phis_n = enc.forward(s_n).clone()
+        phis_n = enc.forward(s_n)                  # every pass returns buffers of its own: no copy needed to keep these
         phis = enc.forward(s)
         critic.learn(None, a, r, None, phis=phis, phis_next=phis_n)
         actor.learn(None, critic, phis=phis)
