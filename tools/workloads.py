@@ -11,6 +11,7 @@
 * `conv_universe_84_b4096` -- the same update behind the two-convolution "universe" head on 84x84x4 float32 frames
   (Conv_model.py:36-56): 41x41x32 -> 20x20x32 = 12,800 features -> the 256-unit ELU layer.
 * `pixel_curious_gan_universe_42_b32` -- the pixel iteration at the reference's own batch of 32 (Curious_GAN_mario.py:393).
+* `conv_universe_84_b32` -- the 84x84 universe-head update at that batch of 32.
 
 bench.py times them after its headline workload (`other_workloads` in its JSON line); run directly it prints them.
 Every entry carries a `roofline` object: the algorithmic multiply-accumulates of one step (`step_macs`, below) against the
@@ -211,6 +212,7 @@ WORKLOADS = (
     ("conv_universe_84_b4096", conv_universe_84, None, lambda: encoder_update_macs(84, [(32, 3, 2)] * 2), FRAME_BYTES_84),
     ("pixel_curious_gan_universe_42_b4096", pixel_curious_gan, None, pixel_iteration_macs, 0),
     ("pixel_curious_gan_universe_42_b32", pixel_curious_gan, 32, pixel_iteration_macs, 0),
+    ("conv_universe_84_b32", conv_universe_84, 32, lambda: encoder_update_macs(84, [(32, 3, 2)] * 2), FRAME_BYTES_84),
 )
 
 
