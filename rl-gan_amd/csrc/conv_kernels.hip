@@ -730,26 +730,6 @@ __host__ __device__ inline DxClass dx_class(const ConvG& g, int cls) {
   c.NG = cdiv(c.Kc, 16);
   return c;
 }
-// The dZ image of conv_dx_img_kernel in LDS with a border of zeros, so that a tap that falls outside the map is an
-// ordinary read: `pt` rows above (the deepest tap row of any class), rows below up to the last pixel row of any class,
-// and ONE run of `pc` zero pixels after every row that serves as the right border of its row and the left border of
-// the next (plus `pl` pixels in front of the first row).  Pixel (r, c) is at lead + (r + pt) * Wp + c.
-struct DxPad { int pt, pl, Hp, Wp; };
-__host__ __device__ inline DxPad dx_pad(const ConvG& g) {
-  int pt = 0, pl = 0, amax = 0, bmax = 0;
-  for (int cls = 0; cls < g.s * g.s; ++cls) {
-    const int py = cls / g.s, px = cls % g.s;
-    const int nky = py < g.k ? (g.k - py + g.s - 1) / g.s : 0, nkx = px < g.k ? (g.k - px + g.s - 1) / g.s : 0;
-    const int na = py < g.H ? (g.H - py + g.s - 1) / g.s : 0, nb = px < g.W ? (g.W - px + g.s - 1) / g.s : 0;
-    if (nky == 0 || nkx == 0) continue;
-    pt = nky - 1 > pt ? nky - 1 : pt; pl = nkx - 1 > pl ? nkx - 1 : pl;
-    amax = na > amax ? na : amax; bmax = nb > bmax ? nb : bmax;
-  }
-  const int pb = amax > g.Ho ? amax - g.Ho : 0, pr = bmax > g.Wo ? bmax - g.Wo : 0;
-  DxPad d;
-  d.pt = pt; d.pl = pl; d.Hp = g.Ho + pt + pb; d.Wp = g.Wo + (pl > pr ? pl : pr);
-  return d;
-}
 struct DxOff {                             // per class: float offset of its fragment image, divisors na*nb and nb, k-groups
   int off[MAX_CLASSES];
   FastDiv dper[MAX_CLASSES], dnb[MAX_CLASSES];
@@ -982,20 +962,23 @@ constexpr int DXI_MAXF = 16;               // kernel fragments (k-groups x input
 // (loops unrolled: the gathers of a tile are all requested before its first MFMA), 0 = any count up to DXI_MAXF / NT.
 template <int NT, int NGC>
 __device__ __forceinline__ void dx_img_class(const ConvG& g, const DxClass& c, FastDiv dnb, const float* __restrict__ Z, int ZS,
-                                             const int* __restrict__ tapd,
-                                             const float* __restrict__ wl, float* __restrict__ dx0, int imgs, int Wp, int img_floats) {
+                                             const int* __restrict__ tapd, const int* __restrict__ tapuv,
+                                             const float* __restrict__ wl, float* __restrict__ dx0, int imgs, int zero_at) {
   constexpr int MAXG = NGC > 0 ? NGC : DXI_MAXF / NT;
   const int lane = threadIdx.x & 63, wave = wave_id(), q0 = lane >> 4;
   const int ng = NGC > 0 ? NGC : c.NG;
   const int per = c.na * c.nb, ntiles = cdiv(per, 16);
   f32x4 w[MAXG * NT];
-  int td[MAXG];
+  int td[MAXG], tu[MAXG], tv[MAXG];
 #pragma unroll
   for (int gi = 0; gi < MAXG; ++gi) {
-    const bool in = gi < ng;                              // a group past the class's: zero fragments times any pixel of the image
+    const bool in = gi < ng;
 #pragma unroll
     for (int i = 0; i < NT; ++i) w[gi * NT + i] = in ? *(const f32x4*)(wl + (gi * NT + i) * 256) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const int tuv = in ? tapuv[4 * gi + q0] : -1;
     td[gi] = in ? tapd[4 * gi + q0] : 0;
+    tu[gi] = tuv < 0 ? 0x10000 : (tuv & 0xffff);          // a tap outside the class's list: a row no pixel has
+    tv[gi] = tuv < 0 ? 0 : (tuv >> 16);
   }
   // the (image, tile) pairs of the workgroup's images go round the waves
   int img = 0, t = wave;
@@ -1003,11 +986,17 @@ __device__ __forceinline__ void dx_img_class(const ConvG& g, const DxClass& c, F
   for (; img < imgs;) {
     const int p = min(16 * t + (lane & 15), per - 1);
     const int a = fdiv(p, dnb), bb = p - a * c.nb;
-    const int pz = img * img_floats + (a * Wp + bb) * ZS;   // Z points at pixel (0, 0) of the first image
+    const int pz = (img * g.Ho * g.Wo + a * g.Wo + bb) * ZS;
     float* dxn = dx0 + (size_t)img * g.H * g.W * g.Cin;
     f32x4 ad[MAXG];
 #pragma unroll
-    for (int gi = 0; gi < MAXG; ++gi) ad[gi] = *(const f32x4*)(Z + pz + td[gi]);   // a tap outside the map lands in the border of zeros
+    for (int gi = 0; gi < MAXG; ++gi) {
+      // a tap outside the map reads the row of zeros behind the images: one select, nothing to clear afterwards.
+      // (A border of zeros around every image, which needs no select at all, was measured: the larger images leave
+      // three instead of four to a workgroup and the result is 5 % slower.)
+      const bool ok = (unsigned)(a - tu[gi]) < (unsigned)g.Ho && (unsigned)(bb - tv[gi]) < (unsigned)g.Wo;
+      ad[gi] = *(const f32x4*)(Z + (ok ? pz + td[gi] : zero_at));
+    }
     f32x4 acc[NT];
 #pragma unroll
     for (int i = 0; i < NT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1042,12 +1031,10 @@ __global__ __launch_bounds__(256) void conv_dx_img_kernel(const ConvG g, const D
   const int ZS = g.Cout + 4, C4 = g.Cout >> 2;
   const int n = blockIdx.x * imgs_per_wg, imgs = min(imgs_per_wg, n_images - n);
   const int npix = imgs * g.Ho * g.Wo;                   // the images of this workgroup, one after the other
-  const DxPad pad = dx_pad(g);
-  const int img_floats = (pad.pl + pad.Hp * pad.Wp) * ZS;                  // one bordered image
-  float* Z = lds + (pad.pl + pad.pt * pad.Wp) * ZS;      // pixel (0, 0) of the first image
-  int* tab = (int*)(lds + imgs_per_wg * img_floats);     // per class: [max_ng * 4] offsets (the second half of each class's entries is unused)
-  for (int i = threadIdx.x * 4; i < imgs_per_wg * img_floats; i += 1024) *(f32x4*)(lds + i) = f32x4{0.f, 0.f, 0.f, 0.f};
-  __syncthreads();                                       // the borders are zero before any pixel is written
+  float* Z = lds;                                        // [imgs][Ho * Wo][Cout + 4], then one row of zeros
+  const int zero_at = imgs_per_wg * g.Ho * g.Wo * ZS;
+  int* tab = (int*)(lds + zero_at + ZS);                 // per class: [max_ng * 4] offsets, then [max_ng * 4] taps
+  if (threadIdx.x < ZS) Z[zero_at + threadIdx.x] = 0.f;
   const int ncls = g.s * g.s, tl = offs.max_ng * 4;
   const f32x4* dz4 = (const f32x4*)(dz + (size_t)n * g.Ho * g.Wo * g.Cout);
   const f32x4* y4 = (const f32x4*)(yelu + (size_t)n * g.Ho * g.Wo * g.Cout);
@@ -1066,8 +1053,8 @@ __global__ __launch_bounds__(256) void conv_dx_img_kernel(const ConvG g, const D
     for (int u = 0; u < SU; ++u) {
       const int i = i0 + 256 * u;
       if (i < npix * C4) {
-        const int p = i / C4, im = fdiv(p, g.dHoWo), r = p - im * (g.Ho * g.Wo), oy = fdiv(r, g.dWo), ox = r - oy * g.Wo;
-        *(f32x4*)(Z + im * img_floats + (oy * pad.Wp + ox) * ZS + 4 * (i - p * C4)) = f32x4{z[u][0] * elu_d(y[u][0]), z[u][1] * elu_d(y[u][1]), z[u][2] * elu_d(y[u][2]), z[u][3] * elu_d(y[u][3])};
+        const int p = i / C4;
+        *(f32x4*)(Z + p * ZS + 4 * (i - p * C4)) = f32x4{z[u][0] * elu_d(y[u][0]), z[u][1] * elu_d(y[u][1]), z[u][2] * elu_d(y[u][2]), z[u][3] * elu_d(y[u][3])};
       }
     }
   }
@@ -1077,22 +1064,23 @@ __global__ __launch_bounds__(256) void conv_dx_img_kernel(const ConvG g, const D
     const int kk0 = q * 4, tap = c.nkx > 0 ? kk0 / g.Cout : 0, co = kk0 - tap * g.Cout;
     const int u = c.nkx > 0 ? tap / c.nkx : 0, v = tap - u * c.nkx;
     const bool in = kk0 < c.Kc;
-    tab[2 * cls * tl + q] = in ? (-u * pad.Wp - v) * ZS + co : 0;
+    tab[2 * cls * tl + q] = in ? (-u * g.Wo - v) * ZS + co : 0;
+    tab[(2 * cls + 1) * tl + q] = in ? (u | (v << 16)) : -1;
   }
   __syncthreads();
   float* dxn = dx + (size_t)n * g.H * g.W * g.Cin;
   const int imgs_here = imgs;
   for (int cls = 0; cls < ncls; ++cls) {                   // no barrier below: every wave walks the classes at its own pace
     const DxClass c = dx_class(g, cls);
-    const int* tapd = tab + 2 * cls * tl;
+    const int *tapd = tab + 2 * cls * tl, *tapuv = tapd + tl;
     const float* wl = wdx + offs.off[cls] + (threadIdx.x & 63) * 4;
     switch (c.NG) {
       case 0: break;
-      case 1: dx_img_class<NT, 1>(g, c, offs.dnb[cls], Z, ZS, tapd, wl, dxn, imgs_here, pad.Wp, img_floats); break;
-      case 2: dx_img_class<NT, 2>(g, c, offs.dnb[cls], Z, ZS, tapd, wl, dxn, imgs_here, pad.Wp, img_floats); break;
-      case 4: dx_img_class<NT, 4>(g, c, offs.dnb[cls], Z, ZS, tapd, wl, dxn, imgs_here, pad.Wp, img_floats); break;
-      case 8: dx_img_class<NT, 8>(g, c, offs.dnb[cls], Z, ZS, tapd, wl, dxn, imgs_here, pad.Wp, img_floats); break;
-      default: dx_img_class<NT, 0>(g, c, offs.dnb[cls], Z, ZS, tapd, wl, dxn, imgs_here, pad.Wp, img_floats); break;
+      case 1: dx_img_class<NT, 1>(g, c, offs.dnb[cls], Z, ZS, tapd, tapuv, wl, dxn, imgs_here, zero_at); break;
+      case 2: dx_img_class<NT, 2>(g, c, offs.dnb[cls], Z, ZS, tapd, tapuv, wl, dxn, imgs_here, zero_at); break;
+      case 4: dx_img_class<NT, 4>(g, c, offs.dnb[cls], Z, ZS, tapd, tapuv, wl, dxn, imgs_here, zero_at); break;
+      case 8: dx_img_class<NT, 8>(g, c, offs.dnb[cls], Z, ZS, tapd, tapuv, wl, dxn, imgs_here, zero_at); break;
+      default: dx_img_class<NT, 0>(g, c, offs.dnb[cls], Z, ZS, tapd, tapuv, wl, dxn, imgs_here, zero_at); break;
     }
   }
 }
@@ -1845,13 +1833,12 @@ int rlgan_conv_backward_input(const rlgan_conv_t* conv, const float* dz, const f
     DxOff offs;
     if (dx_layout(g, &offs) == 0) return RLGAN_E_DIMS;
     const int ntc = cdiv(g.Cin, 16);
-    const DxPad pad = dx_pad(g);
-    const size_t zimg = (size_t)(pad.pl + pad.Hp * pad.Wp) * (g.Cout + 4) * sizeof(float), tabs = (size_t)2 * g.s * g.s * std::max(1, offs.max_ng) * 4 * sizeof(int);
+    const size_t zimg = (size_t)g.Ho * g.Wo * (g.Cout + 4) * sizeof(float), tabs = (size_t)2 * g.s * g.s * std::max(1, offs.max_ng) * 4 * sizeof(int);
     // images per workgroup: a class's kernel fragments are fetched once per workgroup, so several small images share them
     // (with few images, fewer per workgroup: at a batch of 32 four images each left eight workgroups for the whole chip)
     int ipw = (int)std::max<size_t>(1, std::min<size_t>(8, (48 * 1024 - tabs) / zimg));
     while (ipw > 1 && cdiv(n_images, ipw) < 512) --ipw;
-    const size_t ilds = ipw * zimg + tabs;                                   // the bordered images, the tap tables
+    const size_t ilds = ipw * zimg + (g.Cout + 4) * sizeof(float) + tabs;    // the images, a row of zeros, the tap tables
     const bool few = n_images < 64;     // not even a workgroup per four compute units: the per-pixel-group kernel below spreads wider
     if (!few && ntc <= 2 && offs.max_ng * ntc <= DXI_MAXF && ilds <= 64 * 1024 && !(((uintptr_t)dx | (uintptr_t)dz | (uintptr_t)y_elu) & 15)) {
       // pixels no class covers (stride beyond the kernel) keep the zeros of the other kernel's classes: every class
