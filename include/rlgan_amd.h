@@ -431,6 +431,12 @@ int rlgan_dense_backward_input_split(const float* dz, int lddz, const float* wb,
                                      float* slabs, int n_slabs, void* stream);
 int rlgan_dense_backward_weights(const float* x, int ldx, const float* dz, int lddz, float* gwb, int m, int k, int n,
                                  float* slabs, int n_slabs, void* stream);
+/* The kernel gradient alone, gw[k, n] = x^T * dz (slabs of k * n floats): for a caller that takes the bias gradient from
+ * elsewhere, like the transposed convolutions below (their bias is added after the placement, Conv_model.py:457-473, so
+ * its gradient is a column sum of dY, not of this product's dz).  With k a multiple of 64 the ones row of
+ * rlgan_dense_backward_weights would cost a row of 64-row tiles of its own. */
+int rlgan_dense_backward_kernel(const float* x, int ldx, const float* dz, int lddz, float* gw, int m, int k, int n,
+                                float* slabs, int n_slabs, void* stream);
 
 /* ---- transposed convolutions of the pixel generator's decoder --------------------------------------
  * tf.layers.conv2d_transpose(net, c_out, k, strides=stride) on NHWC tensors, padding 'valid', the decoder
@@ -440,7 +446,7 @@ int rlgan_dense_backward_weights(const float* x, int ldx, const float* dz, int l
  * A layer runs as   cols = x2d * Wmat   (rlgan_dense_forward, x2d = [n*h*w][c_in], Wmat = [c_in + 1][kk] with a
  * zero last row, kk = k*k*c_out; filled from canon through rlgan_deconv_build_map and rlgan_pack_weights),
  * then rlgan_deconv_place.  Backward: rlgan_deconv_gather (dcols from dY), rlgan_dense_backward_input (dX),
- * rlgan_dense_backward_weights + rlgan_gather_map (kernel gradient in canonical order), rlgan_column_sums
+ * rlgan_dense_backward_kernel + rlgan_gather_map (kernel gradient in canonical order), rlgan_column_sums
  * (bias gradient). */
 typedef struct { int32_t h, w, c_in, c_out, k, stride; } rlgan_deconv_t;
 typedef struct { int32_t h_out, w_out, kk, n_params, wmat_floats, colsum_floats; } rlgan_deconv_geom_t;

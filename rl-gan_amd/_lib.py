@@ -229,6 +229,7 @@ PROTOTYPES = {
     "rlgan_dense_backward_input": [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp],
     "rlgan_dense_backward_input_split": [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp],
     "rlgan_dense_backward_weights": [_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _i, _vp],
+    "rlgan_dense_backward_kernel": [_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _i, _vp],
 }
 
 for _name, _args in PROTOTYPES.items():

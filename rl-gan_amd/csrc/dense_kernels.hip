@@ -309,4 +309,12 @@ int rlgan_dense_backward_weights(const float* x, int ldx, const float* dz, int l
   return launch_gemm<false, false>(g, slabs, n_slabs, stream);
 }
 
+int rlgan_dense_backward_kernel(const float* x, int ldx, const float* dz, int lddz, float* gw, int m, int k, int n,
+                                float* slabs, int n_slabs, void* stream) {
+  if (ldx < k || lddz < n) return RLGAN_E_ARG;
+  // the same product without the ones row: a k that is a multiple of the 64-row tile gets no extra row of tiles for it
+  GemmArgs g{x, dz, gw, ldx, lddz, n, k, n, m, /*a_x*/ k, /*a_k*/ m, /*b_x*/ n, /*b_k*/ m, /*ones_x*/ -1, /*ones_k*/ -1, 0, 0, 0};
+  return launch_gemm<false, false>(g, slabs, n_slabs, stream);
+}
+
 }  // extern "C"

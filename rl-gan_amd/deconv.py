@@ -133,10 +133,10 @@ class DeconvLayer:
             return dx
         dcols = self._cols_buffer(rows)
         check(lib.rlgan_deconv_gather(self.spec, dy.data_ptr(), yr, dcols.data_ptr(), n, _stream()), "rlgan_deconv_gather")
-        sc, ns = self._slabs(self.c_in + 1, self.kk, rows)
-        check(lib.rlgan_dense_backward_weights(x.data_ptr(), self.c_in, dcols.data_ptr(), self.kk, self._gmat.data_ptr(), rows, self.c_in,
-                                               self.kk, None if sc is None else sc.data_ptr(), ns, _stream()),
-              "rlgan_dense_backward_weights")
+        sc, ns = self._slabs(self.c_in, self.kk, rows)            # the kernel gradient alone: the bias gradient is a column sum of dy (below)
+        check(lib.rlgan_dense_backward_kernel(x.data_ptr(), self.c_in, dcols.data_ptr(), self.kk, self._gmat.data_ptr(), rows, self.c_in,
+                                              self.kk, None if sc is None else sc.data_ptr(), ns, _stream()),
+              "rlgan_dense_backward_kernel")
         nk = self.kk * self.c_in
         check(lib.rlgan_gather_map(self._gmat.data_ptr(), self.map_w.data_ptr(), nk, self.grad.data_ptr(), _stream()), "rlgan_gather_map")
         check(lib.rlgan_column_sums(dy.data_ptr(), yr, n * self.h_out * self.w_out, self.c_out, self._colsum.data_ptr(),
