@@ -537,17 +537,18 @@ __global__ __launch_bounds__(256) void deconv_narrow_bwd_kernel(const float* __r
   }
 }
 
-// grad[p] = sum over chunks of slabs[chunk][p], chunks in order, eight loads in flight
+// grad[p] = sum over chunks of slabs[chunk][p], chunks in order, 32 loads in flight (no branch around a load)
 __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ slabs, int n_chunks, int n, float* __restrict__ grad) {
   const int p = blockIdx.x * 256 + threadIdx.x;
   if (p >= n) return;
+  constexpr int FL = 32;
   float tot = 0.f;
-  for (int c0 = 0; c0 < n_chunks; c0 += 8) {
-    float v[8];
+  for (int c0 = 0; c0 < n_chunks; c0 += FL) {
+    float v[FL];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = c0 + i < n_chunks ? slabs[(size_t)(c0 + i) * n + p] : 0.f;
+    for (int i = 0; i < FL; ++i) v[i] = slabs[(size_t)min(c0 + i, n_chunks - 1) * n + p];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) tot += v[i];
+    for (int i = 0; i < FL; ++i) tot += c0 + i < n_chunks ? v[i] : 0.f;
   }
   grad[p] = tot;
 }
