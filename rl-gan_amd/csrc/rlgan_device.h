@@ -839,15 +839,17 @@ __device__ __forceinline__ void load_x0(float* x0, int row0, int n_rows, MatIn b
 // workgroup barrier of its own).
 //   a: aw columns are read (rows of a matrix in memory, or of an LDS tile when a_local), columns aw .. ap-1 are zero
 //   (the parameter blocks' padding), column ap holds the constant 1
+template <int NW = 4>
 __device__ __forceinline__ void load_xw(float* x0, int row0, int n_rows, const float* __restrict__ phis, int ldp,
                                         const float* a, int lda, int a_local, int aw, int ap, float* x0_global) {
-  for (int e = threadIdx.x; e < ROWS * (PIX_FEATURES / 4); e += THREADS) {
+  constexpr int NTHR = NW * 64;
+  for (int e = threadIdx.x; e < ROWS * (PIX_FEATURES / 4); e += NTHR) {
     const int r = e / (PIX_FEATURES / 4), c4 = e - r * (PIX_FEATURES / 4), gr = row0 + r;
     f32x4 v{0.f, 0.f, 0.f, 0.f};
     if (gr < n_rows) v = *(const f32x4*)(phis + (size_t)gr * ldp + 4 * c4);
     *(f32x4*)(x0 + r * LD_XW + 4 * c4) = v;
   }
-  {
+  if (NW == 4 || threadIdx.x < 256) {                     // one thread per element of the 16x16 tail
     const int r = threadIdx.x >> 4, c = threadIdx.x & 15, gr = row0 + r;
     float v = 0.f;
     if (c < aw && gr < n_rows) v = a_local ? a[r * lda + c] : a[(size_t)gr * lda + c];
@@ -856,7 +858,7 @@ __device__ __forceinline__ void load_xw(float* x0, int row0, int n_rows, const f
   }
   if (x0_global) {
     lds_barrier();
-    for (int e = threadIdx.x; e < 4 * XW_COLS; e += THREADS) {
+    for (int e = threadIdx.x; e < 4 * XW_COLS; e += NTHR) {
       const int b = e / XW_COLS, c = e - b * XW_COLS;
       const float* xp = x0 + (4 * b) * LD_XW + c;
       *(f32x4*)(x0_global + work_off(XW_COLS, 4 * b, c)) = f32x4{xp[0], xp[LD_XW], xp[2 * LD_XW], xp[3 * LD_XW]};
