@@ -1348,6 +1348,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_c4_kernel(const ConvG g, const
   const int n0 = blockIdx.x * per_wg, n1 = min(n_images, n0 + per_wg);
   // An image's operands travel memory -> registers while the previous image is multiplied out of LDS: XU input pixels
   // and ZU four-channel pieces of dY and of the layer output per thread (the host checked that these cover an image).
+  // (Items of four pixels by four channels, transposed in registers and stored as four 16-byte pieces without bank
+  // conflicts, were measured: 115 -> 121 us per 4096 frames -- the stores are not what this kernel waits for.)
   const int C4 = g.Cout >> 2, total = npix * C4;
   typename S::Raw xr[XU];
   f32x4 dr[ZU], yr[ZU];

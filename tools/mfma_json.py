@@ -21,21 +21,34 @@ import sqlite3
 import sys
 
 PEAK_HZ, SIMDS = 2.4e9, 1024
+FULL = "--full-names" in sys.argv          # key kernels by name AND template arguments (a workload with many instances of one template)
+if FULL:
+    sys.argv.remove("--full-names")
+
+
+def key_of(name):
+    if not FULL:
+        m = re.search(r"(\w+_kernel)", name)
+        return m.group(1) if m else None
+    n = name.replace("(anonymous namespace)::", "").replace("void ", "").strip()
+    n = n.split("(")[0].strip()
+    return n if n.endswith(">") or n.endswith("_kernel") else None
+
 
 db = sqlite3.connect(sys.argv[1])
 cols = [d[0] for d in db.execute("select * from counters_collection limit 1").description]
 kn = "kernel_name" if "kernel_name" in cols else "name"
 per = {}
 for name, counter, total, n in db.execute(f"select {kn}, counter_name, sum(value), count(*) from counters_collection group by {kn}, counter_name"):
-    m = re.search(r"(\w+_kernel)", name)
-    if m:
-        per.setdefault(m.group(1), {})[counter] = total / n
+    k = key_of(name)
+    if k:
+        per.setdefault(k, {})[counter] = total / n
 dur = {}
 with open(sys.argv[2]) as f:
     for row in csv.DictReader(f):
-        m = re.search(r"(\w+_kernel)", row["Name"])
-        if m:
-            dur[m.group(1)] = float(row["AverageUs"]) * 1e3
+        k = key_of(row["Name"])
+        if k:
+            dur[k] = float(row["AverageUs"]) * 1e3
 kernels = {}
 for k, c in sorted(per.items()):
     e = {"counters_per_launch": {n: round(v, 1) for n, v in sorted(c.items())}}
