@@ -1,4 +1,4 @@
-"""The two pixel configurations bench.py times after its headline workload (tools/workloads.py) build and step at a small
+"""The pixel configurations bench.py times after its headline workload (tools/workloads.py) build and step at a small
 batch: a workload that raised would show up in the bench line as an error string instead of a number."""
 import os
 import sys
@@ -14,13 +14,14 @@ def test_other_workloads_build_and_step():
     import workloads
     out = workloads.run_all(B=48, seconds=0.05)
     assert [o["workload"] for o in out] == ["conv_ddpg_doom_84_b4096", "conv_universe_84_b4096",
-                                            "pixel_curious_gan_universe_42_b4096", "pixel_curious_gan_universe_42_b32"]
+                                            "pixel_curious_gan_universe_42_b4096", "pixel_curious_gan_universe_42_b32",
+                                            "conv_universe_84_b32"]
     for o in out:
         assert "error" not in o, o
         assert o["value"] > 0 and o["unit"] == "updates/s" and o["steps"] >= 5
         r = o["roofline"]
         assert r["bound"] in ("hbm", "mfma") and 0 < r["frac"] < 1 and r["algorithmic_gflop"] > 0
-    assert out[0]["batch"] == 48 and out[3]["batch"] == 32
+    assert out[0]["batch"] == 48 and out[3]["batch"] == 32 and out[4]["batch"] == 32
 
 
 def test_workload_multiply_accumulate_counts():
