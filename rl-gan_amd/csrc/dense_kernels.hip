@@ -274,12 +274,22 @@ extern "C" {
 int rlgan_dense_slabs(int m_out, int n_out, int k_red) {
   if (m_out <= 0 || n_out <= 0 || k_red <= 0) return RLGAN_E_ARG;
   const long long tiles = (long long)cdiv(m_out, BM) * cdiv(n_out, BN);
-  const int by_chip = (int)std::min<long long>(256, cdiv(1024, tiles));       // about four workgroups per compute unit
-  // at least four reduction steps each; two when the result is a single row tile high (a batch of 32 or 64: every
-  // product is then a few workgroups walking a chain of memory round trips; the pixel iteration at batch 32 ran 6 %
-  // faster).  Results for the batch sizes above that are cut as before, so a row's result is the same bits at 512 and
-  // at 4096 rows.
-  const int by_work = std::max(1, k_red / ((m_out <= BM ? 2 : 4) * BK));
+  if (m_out <= BM) {
+    // a result a single row tile high (a batch of 32 or 64): every product is a few workgroups walking a chain of memory
+    // round trips, so two reduction steps per slab already pay (the pixel iteration at batch 32 ran 6 % faster)
+    const int by_chip = (int)std::min<long long>(256, cdiv(1024, tiles));
+    return std::max(1, std::min(by_chip, std::max(1, k_red / (2 * BK))));
+  }
+  // From a sweep of the pixel networks' products at 4096 and 8192 rows (tools/gemm_slabs.py): a result with two
+  // workgroups' worth of tiles per compute unit is not cut at all (the sum over the slabs would cost more than the
+  // shorter loops save); below that, about four workgroups per compute unit, eight for a result of few tiles (the weight
+  // gradients, whose partial results are small); and slabs of at least eight reduction steps, four when the result is
+  // narrow.  The step bound depends on the layer alone, not on the batch: where it is the smaller of the two (the
+  // generator's layers), a row's result is the same bits whatever the batch.
+  if (tiles >= 512) return 1;
+  const int steps = cdiv(n_out, BN) >= 4 ? 8 : 4;
+  const int by_work = std::max(1, k_red / (steps * BK));
+  const int by_chip = (int)std::min<long long>(32, cdiv(tiles < 200 ? 2048 : 1024, tiles));
   return std::max(1, std::min(by_chip, by_work));
 }
 
