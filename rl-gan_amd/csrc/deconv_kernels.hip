@@ -235,15 +235,27 @@ __global__ __launch_bounds__(256) void sigmoid_ce_kernel(const float* __restrict
                                                          float* __restrict__ loss, float* __restrict__ dlogits) {
   __shared__ float sh[2][256];
   float s[2] = {0.f, 0.f};
-  for (int r = threadIdx.x; r < n_real + n_fake; r += 256) {
-    const float x = logits[(size_t)r * ld];
-    const bool real = r < n_real;
-    const float z = real ? 1.f : 0.f;
-    s[real ? 0 : 1] += fmaxf(x, 0.f) - x * z + log1pf(expf(-fabsf(x)));
-    if (dlogits) {
-      const float sig = 1.f / (1.f + expf(-x));
-      dlogits[(size_t)r * ld] = (sig - z) / (float)(real ? n_real : n_fake);
-      for (int c = 1; c < ld; ++c) dlogits[(size_t)r * ld + c] = 0.f;
+  // eight rows per thread and turn, their loads requested together (a row per turn was a memory round trip per turn:
+  // 32 in a row for 8192 rows); the sums run over a thread's rows in the same order
+  const int n = n_real + n_fake;
+  constexpr int U = 8;
+  for (int r0 = threadIdx.x; r0 < n; r0 += 256 * U) {
+    float xv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) xv[u] = logits[(size_t)min(r0 + 256 * u, n - 1) * ld];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int r = r0 + 256 * u;
+      if (r >= n) break;
+      const float x = xv[u];
+      const bool real = r < n_real;
+      const float z = real ? 1.f : 0.f;
+      s[real ? 0 : 1] += fmaxf(x, 0.f) - x * z + log1pf(expf(-fabsf(x)));
+      if (dlogits) {
+        const float sig = 1.f / (1.f + expf(-x));
+        dlogits[(size_t)r * ld] = (sig - z) / (float)(real ? n_real : n_fake);
+        for (int c = 1; c < ld; ++c) dlogits[(size_t)r * ld + c] = 0.f;
+      }
     }
   }
   sh[0][threadIdx.x] = s[0]; sh[1][threadIdx.x] = s[1];
