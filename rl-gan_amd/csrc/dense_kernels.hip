@@ -16,7 +16,11 @@ using namespace rlgan;
 
 namespace {
 
-constexpr int BM = 64, BN = 64, BK = 32;   // workgroup tile of C and the reduction step
+#ifndef RLGAN_BK
+#define RLGAN_BK 32
+#endif
+constexpr int BM = 64, BN = 64, BK = RLGAN_BK;   // workgroup tile of C and the reduction step
+constexpr int F4R = BK / 4, TL = BK / 16;   // float4 per tile row; float4 per thread and operand tile
 constexpr int LDT = BK + 4;                 // LDS row: 36 floats, the 16 rows of an MFMA lane group fall on disjoint banks
 constexpr int TILE_FLOATS = 64 * LDT;
 
@@ -42,13 +46,13 @@ struct GemmArgs {
 // for each of them where the branches join, and a product whose tiles are all border tiles (an output 4 to 16
 // columns wide) spent a memory latency per element group: 19-30 us for layers of a few thousand multiply-adds per row.
 template <bool KCONT>
-__device__ __forceinline__ void tile_load(f32x4 (&r)[2], const float* __restrict__ p, int ld, int x0, int k0, int nx, int nk,
+__device__ __forceinline__ void tile_load(f32x4 (&r)[TL], const float* __restrict__ p, int ld, int x0, int k0, int nx, int nk,
                                           int ones_x, int ones_k) {
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
+  for (int h = 0; h < TL; ++h) {
     const int u = threadIdx.x + 256 * h;
     int x, k;
-    if (KCONT) { x = x0 + (u >> 3); k = k0 + (u & 7) * 4; }
+    if (KCONT) { x = x0 + u / F4R; k = k0 + (u % F4R) * 4; }
     else       { k = k0 + (u >> 4); x = x0 + (u & 15) * 4; }
     f32x4 v;
     if (KCONT) {
@@ -77,11 +81,11 @@ __device__ __forceinline__ void tile_load(f32x4 (&r)[2], const float* __restrict
 // (Conditions around the loads make the wave wait for them where the branches join, i.e. before the
 // multiplications they are meant to overlap with; the main loop below therefore runs on this form alone.)
 template <bool KCONT>
-__device__ __forceinline__ void tile_load_inside(f32x4 (&r)[2], const float* __restrict__ p, int ld, int x0, int k0) {
+__device__ __forceinline__ void tile_load_inside(f32x4 (&r)[TL], const float* __restrict__ p, int ld, int x0, int k0) {
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
+  for (int h = 0; h < TL; ++h) {
     const int u = threadIdx.x + 256 * h;
-    r[h] = KCONT ? *(const f32x4*)(p + (size_t)(x0 + (u >> 3)) * ld + k0 + (u & 7) * 4)
+    r[h] = KCONT ? *(const f32x4*)(p + (size_t)(x0 + u / F4R) * ld + k0 + (u % F4R) * 4)
                  : *(const f32x4*)(p + (size_t)(k0 + (u >> 4)) * ld + x0 + (u & 15) * 4);
   }
 }
@@ -91,12 +95,12 @@ __device__ __forceinline__ void tile_load_inside(f32x4 (&r)[2], const float* __r
 __device__ __forceinline__ int swz(int x, int k) { return k ^ (((x >> 4) & 3) << 2); }
 // the registers of tile_load into an LDS tile [64 x][LDT], k contiguous
 template <bool KCONT>
-__device__ __forceinline__ void tile_store(float* t, const f32x4 (&r)[2]) {
+__device__ __forceinline__ void tile_store(float* t, const f32x4 (&r)[TL]) {
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
+  for (int h = 0; h < TL; ++h) {
     const int u = threadIdx.x + 256 * h;
     if (KCONT) {
-      *(f32x4*)(t + (u >> 3) * LDT + swz(u >> 3, (u & 7) * 4)) = r[h];
+      *(f32x4*)(t + (u / F4R) * LDT + swz(u / F4R, (u % F4R) * 4)) = r[h];
     } else {
       const int k = u >> 4, x = (u & 15) * 4;        // x .. x+3 lie in one 16-row block
 #pragma unroll
@@ -112,7 +116,7 @@ __device__ __forceinline__ void tile_store(float* t, const f32x4 (&r)[2]) {
 // slabs, which every product can now ask for.)
 template <bool A_KCONT, bool B_KCONT>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
-  __shared__ __attribute__((aligned(16))) float lds[4 * TILE_FLOATS];   // A and B tiles, two stages
+  extern __shared__ __attribute__((aligned(16))) float lds[];           // 4 * TILE_FLOATS: A and B tiles, two stages
   // consecutive workgroups share the A tile (same rows, neighbouring column tiles)
   const int ntn = cdiv(g.N, BN);
   const int m0 = ((int)blockIdx.x / ntn) * BM, n0 = ((int)blockIdx.x % ntn) * BN;
@@ -120,7 +124,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
   const int q4 = (lane >> 4) * 4, j = lane & 15;
   const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
   const int ax = g.a_x, ak = g.a_k;
-  f32x4 ra[2], rb[2];
+  f32x4 ra[TL], rb[TL];
   f32x4 acc[2][2];
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
@@ -250,18 +254,20 @@ int launch_gemm(GemmArgs g, float* slabs, int n_slabs, void* stream) {
   const long long blocks = (long long)cdiv(g.M, BM) * cdiv(g.N, BN);
   if (blocks > 0x7fffffffll) return RLGAN_E_ARG;
   g.k_split = g.K; g.slab = 0;
+  constexpr size_t GEMM_LDS = (size_t)4 * TILE_FLOATS * sizeof(float);
+  if (GEMM_LDS > 64 * 1024) (void)hipFuncSetAttribute((const void*)gemm_kernel<A_KCONT, B_KCONT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS);
   int nz = 1;
   if (n_slabs > 1) {
     g.k_split = BK * cdiv(cdiv(g.K, n_slabs), BK);
     nz = cdiv(g.K, g.k_split);
   }
   if (nz == 1) {
-    hipLaunchKernelGGL((gemm_kernel<A_KCONT, B_KCONT>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g);
+    hipLaunchKernelGGL((gemm_kernel<A_KCONT, B_KCONT>), dim3((unsigned)blocks), dim3(256), GEMM_LDS, (hipStream_t)stream, g);
     return launched();
   }
   float* out = g.c; const int ldc = g.ldc, act = g.act;
   g.c = slabs; g.ldc = g.N; g.act = 0; g.slab = (size_t)g.M * g.N;
-  hipLaunchKernelGGL((gemm_kernel<A_KCONT, B_KCONT>), dim3((unsigned)blocks, nz), dim3(256), 0, (hipStream_t)stream, g);
+  hipLaunchKernelGGL((gemm_kernel<A_KCONT, B_KCONT>), dim3((unsigned)blocks, nz), dim3(256), GEMM_LDS, (hipStream_t)stream, g);
   hipLaunchKernelGGL(split_sum_kernel, dim3((unsigned)cdiv((long long)g.M * g.N, 256)), dim3(256), 0, (hipStream_t)stream,
                      slabs, nz, g.slab, g.M, g.N, out, ldc, act);
   return launched();
@@ -278,7 +284,7 @@ int rlgan_dense_slabs(int m_out, int n_out, int k_red) {
     // a result a single row tile high (a batch of 32 or 64): every product is a few workgroups walking a chain of memory
     // round trips, so two reduction steps per slab already pay (the pixel iteration at batch 32 ran 6 % faster)
     const int by_chip = (int)std::min<long long>(256, cdiv(1024, tiles));
-    return std::max(1, std::min(by_chip, std::max(1, k_red / (2 * BK))));
+    return std::max(1, std::min(by_chip, std::max(1, k_red / (2 * 32))));
   }
   // From a sweep of the pixel networks' products at 4096 and 8192 rows (tools/gemm_slabs.py): a result with two
   // workgroups' worth of tiles per compute unit is not cut at all (the sum over the slabs would cost more than the
@@ -288,7 +294,7 @@ int rlgan_dense_slabs(int m_out, int n_out, int k_red) {
   // generator's layers), a row's result is the same bits whatever the batch.
   if (tiles >= 512) return 1;
   const int steps = cdiv(n_out, BN) >= 4 ? 8 : 4;
-  const int by_work = std::max(1, k_red / (steps * BK));
+  const int by_work = std::max(1, k_red / (steps * 32));
   const int by_chip = (int)std::min<long long>(32, cdiv(tiles < 200 ? 2048 : 1024, tiles));
   return std::max(1, std::min(by_chip, by_work));
 }
