@@ -253,8 +253,9 @@ struct FragSrc {
 // whole (three each), and of the last tile every wave computes the k-groups w, w+4, w+8, (w+12) as further
 // steps of its stream; the four partial sums meet in LDS (`spart`, slot = rotated wave index, added in slot
 // order) and all threads of the workgroup apply the epilogue to that tile, one element each, behind one more barrier.
+// (depths 4 / 5 / 6 / 7 / 8 / 12 measured on the headline step, same box: 0.1726 / 0.1708 / 0.1693 / 0.1701 / 0.1704 / 0.1732 ms)
 #ifndef RLGAN_RING
-#define RLGAN_RING 8
+#define RLGAN_RING 6
 #endif
 constexpr int RING = RLGAN_RING;
 
