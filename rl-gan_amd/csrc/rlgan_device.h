@@ -345,10 +345,14 @@ __device__ __forceinline__ void dense_tiles(Pre<NT, NG, NW>& p, const float* xq,
   auto a_at = [&](int s) {
     return *(const f32x4*)(xq + 16 * (s < SW ? s % NG : min(sw + NSH * (s - SW), NG - 1)));
   };
-  f32x4 ar[3];
+#ifndef RLGAN_AD
+#define RLGAN_AD 2
+#endif
+  constexpr int AD = RLGAN_AD;                            // steps an A operand is read ahead of its use (1, 2, 3, 4 measured: the step time does not move)
+  f32x4 ar[AD + 1];
   if constexpr (!AREG) {
-    ar[0] = a_at(0);
-    if (S > 1) ar[1] = a_at(1);
+#pragma unroll
+    for (int i = 0; i < AD; ++i) if (i < S) ar[i] = a_at(i);
   }
   f32x4 acc0{0.f, 0.f, 0.f, 0.f}, acc1{0.f, 0.f, 0.f, 0.f};
   f32x4 s0{0.f, 0.f, 0.f, 0.f}, s1{0.f, 0.f, 0.f, 0.f};      // the shared tile's partial sums
@@ -364,9 +368,9 @@ __device__ __forceinline__ void dense_tiles(Pre<NT, NG, NW>& p, const float* xq,
       acc0 = f32x4{0.f, 0.f, 0.f, 0.f}; acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     if constexpr (!AREG) {
-      if (s + 2 < S) ar[(s + 2) % 3] = a_at(s + 2);
+      if (s + AD < S) ar[(s + AD) % (AD + 1)] = a_at(s + AD);
     }
-    const f32x4 av = AREG ? areg : ar[s % 3];
+    const f32x4 av = AREG ? areg : ar[s % (AD + 1)];
     const f32x4 bv = p.b[s % DS];
     if (whole) {
       acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], bv[0], acc0, 0, 0, 0);
