@@ -101,6 +101,30 @@ def test_dense_input_gradient_in_slabs(m, k, n, ns):
     assert _lib.lib.rlgan_dense_backward_input_split(dzt.data_ptr(), n, wb.data_ptr(), one.data_ptr(), k, m, k, n, None, 4, None) == -1
 
 
+@pytest.mark.parametrize("m,k,n,ns", [(2304, 128, 1024, 16), (300, 200, 1152, 1), (40, 20, 12, 3)])
+def test_dense_kernel_gradient_without_the_bias_row(m, k, n, ns):
+    """gw[k, n] = x^T dz, the weight gradient of a layer whose bias gradient comes from elsewhere (the transposed
+    convolutions in their cols form): equal to the float64 product, equal to the first k rows of
+    rlgan_dense_backward_weights with the same slabs (same products in the same order), and nothing is written past row k."""
+    from rl_gan_amd import _lib
+    from gpu_util import close
+    rng = np.random.RandomState(k + n)
+    x = rng.standard_normal((m, k)).astype(np.float32)
+    dz = rng.standard_normal((m, n)).astype(np.float32)
+    xt, dzt = torch.from_numpy(x).cuda(), torch.from_numpy(dz).cuda()
+    slabs = torch.empty(max(1, ns) * (k + 1) * n, device="cuda")
+    gw = torch.full(((k + 1), n), float("nan"), device="cuda")
+    assert _lib.lib.rlgan_dense_backward_kernel(xt.data_ptr(), k, dzt.data_ptr(), n, gw.data_ptr(), m, k, n, slabs.data_ptr(), ns, None) == 0
+    got = gw.cpu().numpy()
+    assert np.isnan(got[k]).all()                                            # the row a bias gradient would take is untouched
+    close(got[:k], x.astype(np.float64).T @ dz.astype(np.float64), what="kernel gradient")
+    gwb = torch.empty(((k + 1), n), device="cuda")
+    assert _lib.lib.rlgan_dense_backward_weights(xt.data_ptr(), k, dzt.data_ptr(), n, gwb.data_ptr(), m, k, n, slabs.data_ptr(), ns, None) == 0
+    np.testing.assert_array_equal(got[:k], gwb.cpu().numpy()[:k])
+    close(gwb.cpu().numpy()[k], dz.astype(np.float64).sum(0), what="bias row of the full form")
+    assert _lib.lib.rlgan_dense_backward_kernel(xt.data_ptr(), k - 1, dzt.data_ptr(), n, gw.data_ptr(), m, k, n, None, 1, None) == -1
+
+
 def test_encoder_with_dense_head_end_to_end():
     """doom head + fc(256): features, and the gradient reaching the first conv layer."""
     import rl_gan_amd as R
