@@ -547,6 +547,11 @@ int rlgan_relu_backward(const float* dy, const float* y, float* dz, int64_t n, v
  * [features, action] rows (Conv_model.py:452) with zero columns up to a 16-byte row, and column slices of such rows on
  * the way back (n_zero = 0). */
 int rlgan_copy_cols(const float* src, int ld_src, float* dst, int ld_dst, int64_t rows, int n_copy, int n_zero, void* stream);
+/* The concatenation itself in one launch: dst[r] = [s0[r][0..w0) | s1[r][0..w1) | s2[r][0..w2) | n_zero zeros] for r < rows
+ * (`tf.concat([phis, a], 1)` Conv_model.py:452, `tf.concat([phi1, phi2], 1)` :806, the discriminator's
+ * [phis, features, a] rows :183-199).  A block of width 0 is skipped (its pointer may be null). */
+int rlgan_concat_cols(const float* s0, int ld0, int w0, const float* s1, int ld1, int w1, const float* s2, int ld2, int w2,
+                      float* dst, int ld_dst, int64_t rows, int n_zero, void* stream);
 /* One-channel images [n][h][w] <-> their 2x2 blocks as four channels [n][h/2][w/2][4], channel 2*dy + dx =
  * image[2Y + dy][2X + dx] (h, w even; both buffers 16-byte aligned).  to_blocks != 0: src is the image.  A 3x3
  * stride-2 convolution of the image (`universe_feature_abstraction(single_S_, time_step=1)`, Conv_model.py:36-49,

@@ -207,6 +207,7 @@ PROTOTYPES = {
     "rlgan_gather_map": [_vp, _vp, _i, _vp, _vp],
     "rlgan_relu_backward": [_vp, _vp, _vp, C.c_int64, _vp],
     "rlgan_copy_cols": [_vp, _i, _vp, _i, C.c_int64, _i, _i, _vp],
+    "rlgan_concat_cols": [_vp, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp, _i, C.c_int64, _i, _vp],
     "rlgan_blocks2x2": [_vp, _vp, C.c_int64, _i, _i, _i, _vp],
     "rlgan_add_cols": [_vp, _i, _vp, _i, C.c_int64, _i, _vp],
     "rlgan_sigmoid_ce": [_vp, _i, _i, _i, _vp, _vp, _vp],

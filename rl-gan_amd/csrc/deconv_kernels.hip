@@ -167,6 +167,18 @@ __global__ void copy_cols_kernel(const float* __restrict__ src, int ld_src, floa
   if (c >= n_copy + n_zero) return;
   for (long long r = blockIdx.y; r < rows; r += gridDim.y) dst[r * ld_dst + c] = c < n_copy ? src[r * ld_src + c] : 0.f;
 }
+// up to three column blocks side by side, then zeros: dst[r] = [s0[r][0..w0) | s1[r][0..w1) | s2[r][0..w2) | 0 x n_zero]
+struct ConcatArgs { const float* s[3]; int ld[3], w[3]; float* dst; int ld_dst, n_zero; long long rows; };
+__global__ void concat_cols_kernel(const ConcatArgs A) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int e0 = A.w[0], e1 = e0 + A.w[1], e2 = e1 + A.w[2];
+  if (c >= e2 + A.n_zero) return;
+  const int which = (c >= e0) + (c >= e1) + (c >= e2);               // 3: a zero column
+  const float* src = which == 0 ? A.s[0] : which == 1 ? A.s[1] : A.s[2];
+  const int ld = which == 0 ? A.ld[0] : which == 1 ? A.ld[1] : A.ld[2];
+  const int cc = c - (which == 0 ? 0 : which == 1 ? e0 : e1);
+  for (long long r = blockIdx.y; r < A.rows; r += gridDim.y) A.dst[r * A.ld_dst + c] = which < 3 ? src[r * ld + cc] : 0.f;
+}
 // narrow rows (n_copy + n_zero <= 4: the channel padding): one thread per row
 __global__ void copy_cols_narrow_kernel(const float* __restrict__ src, int ld_src, float* __restrict__ dst, int ld_dst, long long rows,
                                         int n_copy, int n_zero) {
@@ -420,6 +432,19 @@ int rlgan_copy_cols(const float* src, int ld_src, float* dst, int ld_dst, int64_
     hipLaunchKernelGGL(copy_cols_kernel, dim3(cdiv(nc, 256), gy), dim3(256), 0, (hipStream_t)stream,
                        src, ld_src, dst, ld_dst, (long long)rows, n_copy, n_zero);
   }
+  return launched();
+}
+
+int rlgan_concat_cols(const float* s0, int ld0, int w0, const float* s1, int ld1, int w1, const float* s2, int ld2, int w2,
+                      float* dst, int ld_dst, int64_t rows, int n_zero, void* stream) {
+  if (!dst || rows <= 0 || w0 < 0 || w1 < 0 || w2 < 0 || n_zero < 0 || (w0 > 0 && !s0) || (w1 > 0 && !s1) || (w2 > 0 && !s2)) return RLGAN_E_ARG;
+  const long long nc = (long long)w0 + w1 + w2 + n_zero;
+  if (nc <= 0) return RLGAN_E_ARG;
+  if (ld_dst < nc || (w0 > 0 && ld0 < w0) || (w1 > 0 && ld1 < w1) || (w2 > 0 && ld2 < w2)) return RLGAN_E_ALIGN;
+  ConcatArgs A{{s0, s1, s2}, {ld0, ld1, ld2}, {w0, w1, w2}, dst, ld_dst, n_zero, (long long)rows};
+  for (int i = 0; i < 3; ++i) if (A.w[i] == 0) A.s[i] = dst;          // never read; keeps the selects free of null pointers
+  const unsigned gy = (unsigned)std::min<int64_t>(rows, 4096);
+  hipLaunchKernelGGL(concat_cols_kernel, dim3(cdiv((int)nc, 256), gy), dim3(256), 0, (hipStream_t)stream, A);
   return launched();
 }
 

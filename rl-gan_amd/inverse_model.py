@@ -121,9 +121,8 @@ class StateActionPredictor:
             n = s.shape[0]
             f = self.state_encoder.forward(torch.cat([s, s_next], 0).contiguous())
         x = torch.empty((n, 2 * self.h_dim), dtype=torch.float32, device=f.device)
-        for c in range(2):
-            check(lib.rlgan_copy_cols(f.data_ptr() + 4 * c * n * self.h_dim, self.h_dim, x.data_ptr() + 4 * c * self.h_dim, 2 * self.h_dim,
-                                      n, self.h_dim, 0, _stream()), "rlgan_copy_cols")
+        check(lib.rlgan_concat_cols(f.data_ptr(), self.h_dim, self.h_dim, f.data_ptr() + 4 * n * self.h_dim, self.h_dim, self.h_dim,
+                                    None, 0, 0, x.data_ptr(), 2 * self.h_dim, n, 0, _stream()), "rlgan_concat_cols")
         return x
 
     def _net(self, x: torch.Tensor, training: bool):

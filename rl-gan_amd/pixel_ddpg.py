@@ -152,9 +152,8 @@ class LSTMUnit:
         """(c', h') for a batch of features and states, all on the device."""
         n = phis.shape[0]
         x = torch.empty((n, self.h_dim + self.units), dtype=torch.float32, device=phis.device)
-        check(lib.rlgan_copy_cols(phis.data_ptr(), row_ld(phis), x.data_ptr(), x.shape[1], n, self.h_dim, 0, _stream()), "rlgan_copy_cols")
-        check(lib.rlgan_copy_cols(h_in.data_ptr(), row_ld(h_in), x.data_ptr() + 4 * self.h_dim, x.shape[1], n, self.units, 0, _stream()),
-              "rlgan_copy_cols")
+        check(lib.rlgan_concat_cols(phis.data_ptr(), row_ld(phis), self.h_dim, h_in.data_ptr(), row_ld(h_in), self.units, None, 0, 0,
+                                    x.data_ptr(), x.shape[1], n, 0, _stream()), "rlgan_concat_cols")
         gates = self.cell.forward(x, act=False)
         c_in = c_in.contiguous()
         c_out, h_out = torch.empty_like(c_in), torch.empty_like(c_in)
@@ -329,9 +328,8 @@ class PixelCritic:
         """[n, k_pad] rows [phis, a, 0]; a: [n, >= a_dim], its first a_dim columns are used."""
         n = phis.shape[0]
         x = torch.empty((n, self.k_pad), dtype=torch.float32, device=phis.device)
-        check(lib.rlgan_copy_cols(phis.data_ptr(), row_ld(phis), x.data_ptr(), self.k_pad, n, self.h_dim, 0, _stream()), "rlgan_copy_cols")
-        check(lib.rlgan_copy_cols(a.data_ptr(), row_ld(a), x.data_ptr() + 4 * self.h_dim, self.k_pad, n, self.a_dim, self.a_pad - self.a_dim,
-                                  _stream()), "rlgan_copy_cols")
+        check(lib.rlgan_concat_cols(phis.data_ptr(), row_ld(phis), self.h_dim, a.data_ptr(), row_ld(a), self.a_dim, None, 0, 0,
+                                    x.data_ptr(), self.k_pad, n, self.a_pad - self.a_dim, _stream()), "rlgan_concat_cols")
         return x
 
     def q_batch(self, phis: torch.Tensor, a: torch.Tensor, target: bool = False) -> torch.Tensor:

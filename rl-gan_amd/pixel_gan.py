@@ -86,9 +86,8 @@ class PixelGenerator:
     def _input(self, phis: torch.Tensor, a: torch.Tensor) -> torch.Tensor:
         n = phis.shape[0]
         x = torch.empty((n, self.k_pad), dtype=torch.float32, device=phis.device)
-        check(lib.rlgan_copy_cols(phis.data_ptr(), row_ld(phis), x.data_ptr(), self.k_pad, n, self.h_dim, 0, _stream()), "rlgan_copy_cols")
-        check(lib.rlgan_copy_cols(a.data_ptr(), row_ld(a), x.data_ptr() + 4 * self.h_dim, self.k_pad, n, self.a_dim,
-                                  self.k_pad - self.h_dim - self.a_dim, _stream()), "rlgan_copy_cols")
+        check(lib.rlgan_concat_cols(phis.data_ptr(), row_ld(phis), self.h_dim, a.data_ptr(), row_ld(a), self.a_dim, None, 0, 0,
+                                    x.data_ptr(), self.k_pad, n, self.k_pad - self.h_dim - self.a_dim, _stream()), "rlgan_concat_cols")
         return x
 
     def predict_batch(self, phis: torch.Tensor, a: torch.Tensor) -> torch.Tensor:
@@ -213,13 +212,11 @@ class PixelDiscriminator:
         n = phis.shape[0]
         x = torch.empty((copies * n, self.k_pad), dtype=torch.float32, device=phis.device)
         pad = self.k_pad - self.h_dim - self.obs_dim - self.a_dim
-        for c in range(copies):
-            base = x.data_ptr() + 4 * c * n * self.k_pad
-            check(lib.rlgan_copy_cols(phis.data_ptr(), row_ld(phis), base, self.k_pad, n, self.h_dim, 0, _stream()), "rlgan_copy_cols")
-            check(lib.rlgan_copy_cols(a.data_ptr(), row_ld(a), base + 4 * (self.h_dim + self.obs_dim), self.k_pad, n, self.a_dim, pad,
-                                      _stream()), "rlgan_copy_cols")
-        check(lib.rlgan_copy_cols(feats.data_ptr(), row_ld(feats), x.data_ptr() + 4 * self.h_dim, self.k_pad, copies * n, self.obs_dim, 0,
-                                  _stream()), "rlgan_copy_cols")
+        ldf = row_ld(feats)
+        for c in range(copies):                                  # one launch per copy: [phis | this copy's features | a | 0]
+            check(lib.rlgan_concat_cols(phis.data_ptr(), row_ld(phis), self.h_dim, feats.data_ptr() + 4 * c * n * ldf, ldf, self.obs_dim,
+                                        a.data_ptr(), row_ld(a), self.a_dim, x.data_ptr() + 4 * c * n * self.k_pad, self.k_pad, n, pad,
+                                        _stream()), "rlgan_concat_cols")
         return x
 
     def _net(self, x: torch.Tensor):
