@@ -5,7 +5,7 @@ import rl_gan_amd as R
 L = R.CuriousLearner(R.LearnerConfig(n_env=4096, batch_size=4096, memory_capacity=1 << 20, seed=1))
 L.fill(); L.capture()
 t0 = time.perf_counter()
-for i in range(30000):
+for i in range(int(sys.argv[1]) if len(sys.argv) > 1 else 30000):
     L.step()
     if i % 10000 == 9999:
         torch.cuda.synchronize()
