@@ -1428,6 +1428,183 @@ __global__ __launch_bounds__(256) void conv_wgrad_c4_kernel(const ConvG g, const
   }
 }
 
+// Weight gradient of the 3x3 layers with 32 input channels on 20x20 maps (the encoders' second layer) with whole images
+// in LDS and the work of a workgroup divided by KIND of wave.  conv_wgrad_kernel stages 16 pixels of patches at a time
+// behind two barriers; a form where every wave both stages and multiplies whole images was measured at the same time as
+// that kernel: the layer needs 72 KB per image at the rate the matrix pipe could use them, and a workgroup that alternates
+// between the two phases overlaps them only through its neighbour on the compute unit.  Here four waves multiply image n
+// out of one LDS buffer while four others fill the second buffer with image n + 1 (the image as it lies in memory, pixels
+// IMG_PAD floats further apart than their 32 channels so that the four pixels of a row-operand read fall on four
+// quarters of the banks; dY * ELU'(y) transposed to [pixel / 4][channel][4]); one barrier per image.  A 16-row tile of
+// the product is half of one tap's channels, contiguous in LDS; with the map width a template parameter the tap offset
+// is an immediate of the read.  The multiplying waves split the row tiles -- wave (half, set) takes channels
+// 16 half .. +15 of taps 0, 2, 4, 6, 8 (set 0) or of taps 1, 3, 5, 7 and the bias row (set 1; with half 1 that last
+// tile multiplies zeros: the others run five tiles anyway) -- so each owns its part of the result outright.
+constexpr int IMG_PAD = 2;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int SET, int NT, int NG16, int W, int PS>
+__device__ __forceinline__ void wgrad_img_products(const float* const (&xa)[NG16][4], const float* Zq, int Cout, float bias_a,
+                                                   f32x4 (&acc)[5][NT]) {
+  // A step = one pixel of each lane's four in a group: five row operands, ten matrix instructions.  The operands of
+  // step t + 1 (and dZ of the next group before a group's last step) are read from LDS before step t's products are
+  // issued; the fences keep the compiler from reading further ahead (it runs out of registers).
+  float av[2][5];
+  f32x4 bz[2][NT];
+  auto read_step = [&](int t) {
+    const int G = t >> 2, e = t & 3;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int tap = 2 * i + SET;
+      av[t & 1][i] = tap < 9 ? xa[G][e][((tap / 3) * W + tap % 3) * PS] : bias_a;
+    }
+  };
+  auto read_dz = [&](int G) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bz[G & 1][nt] = *(const f32x4*)(Zq + (4 * G * Cout + 16 * nt) * 4);
+  };
+  read_dz(0);
+  read_step(0);
+#pragma unroll
+  for (int t = 0; t < 4 * NG16; ++t) {
+    const int G = t >> 2, e = t & 3;
+    if (t + 1 < 4 * NG16) read_step(t + 1);
+    if (e == 2 && G + 1 < NG16) read_dz(G + 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t & 1][i], bz[G & 1][nt][e], acc[i][nt], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+constexpr int IMG_WAVES = 8, IMG_FILL = 4;                 // waves of a workgroup; how many of them fill (the others multiply, one per SIMD)
+constexpr int IMG_XU = 13, IMG_ZU = 3;                     // pieces of an image per filling thread (20x20x32 in, 9x9x32 out)
+template <int NT, int NG16, int W, class S>
+__global__ __launch_bounds__(IMG_WAVES * 64) void conv_wgrad_img_kernel(const ConvG g, const S src, const float* __restrict__ dz,
+                                                                       const float* __restrict__ yelu, float* __restrict__ slabs,
+                                                                       int n_images, int per_wg) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int CIN = 32, PS = CIN + IMG_PAD, PP = NG16 * 16, FILL_THREADS = IMG_FILL * 64;
+  const int HW = g.H * W, npix = g.Ho * g.Wo, XC4 = HW * (CIN / 4);
+  const int BUF = HW * PS + PP * g.Cout;                  // floats of one buffer: X [H * W][PS], then Zt [PP / 4][Cout][4]
+  const int lane = threadIdx.x & 63, wave = wave_id(), q = lane >> 4, j = lane & 15;
+  for (int i = threadIdx.x; i < 2 * (PP - npix) * g.Cout; i += IMG_WAVES * 64) {   // pixels past the image's last, both buffers: zero, never overwritten
+    const int b = i / ((PP - npix) * g.Cout), r = i - b * ((PP - npix) * g.Cout);
+    const int p = npix + r / g.Cout, co = r % g.Cout;
+    lds[b * BUF + HW * PS + ((p >> 2) * g.Cout + co) * 4 + (p & 3)] = 0.f;
+  }
+  const int n0 = blockIdx.x * per_wg, n1 = min(n_images, n0 + per_wg);
+  const int C4 = g.Cout >> 2, total = npix * C4;
+  // An image on its way through the filling waves: every piece of it (XU four-channel pieces of the image, ZU of dY and
+  // of the layer output per thread; the host checked that these cover an image) is requested before the first is used.
+  const int ft = threadIdx.x - (IMG_WAVES - IMG_FILL) * 64;
+  typename S::Raw xr[IMG_XU];
+  f32x4 dr[IMG_ZU], yr[IMG_ZU];
+  long long base_f = -1;
+  auto fetch = [&](int n) {
+    base_f = src.image(n);
+#pragma unroll
+    for (int u = 0; u < IMG_XU; ++u) xr[u] = src.load_stream(base_f, (size_t)4 * min(ft + FILL_THREADS * u, XC4 - 1));
+    const f32x4* dz4 = (const f32x4*)(dz + (size_t)n * npix * g.Cout);
+    const f32x4* y4 = (const f32x4*)(yelu + (size_t)n * npix * g.Cout);
+#pragma unroll
+    for (int u = 0; u < IMG_ZU; ++u) {
+      const int i = min(ft + FILL_THREADS * u, total - 1);
+      dr[u] = __builtin_nontemporal_load(dz4 + i);
+      yr[u] = yelu ? __builtin_nontemporal_load(y4 + i) : f32x4{1.f, 1.f, 1.f, 1.f};
+    }
+  };
+  auto stash = [&](int b) {
+    float* X = lds + b * BUF;
+    float* Zt = X + HW * PS;
+#pragma unroll
+    for (int u = 0; u < IMG_XU; ++u) {
+      const int i = ft + FILL_THREADS * u;
+      if (i < XC4) {
+        const int pix = i / (CIN / 4), c = 4 * (i % (CIN / 4));
+        const f32x4 v = src.value(xr[u], base_f);
+        float* d = X + pix * PS + c;                     // 8-byte aligned (PS is even)
+        *(f32x2*)d = f32x2{v[0], v[1]};
+        *(f32x2*)(d + 2) = f32x2{v[2], v[3]};
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < IMG_ZU; ++u) {
+      const int i = ft + FILL_THREADS * u;
+      if (i < total) {
+        const int p = i / C4, c0 = 4 * (i - p * C4);
+        float* zt = Zt + ((p >> 2) * g.Cout + c0) * 4 + (p & 3);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) zt[4 * c] = dr[u][c] * elu_d(yr[u][c]);
+      }
+    }
+  };
+  const bool filler = wave >= IMG_WAVES - IMG_FILL;        // wave-uniform
+  const int half = wave & 1, set = (wave >> 1) & 1;           // of the multiplying waves 0 .. 3
+  // this lane's row operand of tap (0, 0) for each of its pixels, in buffer 0 (floats from the start of LDS)
+  int xo[NG16][4];
+#pragma unroll
+  for (int G = 0; G < NG16; ++G) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int pc = min(16 * G + 4 * q + e, npix - 1), oy = fdiv(pc, g.dWo), ox = pc - oy * g.Wo;   // past the last: any pixel (dZ is zero there)
+      xo[G][e] = ((g.s * oy) * W + g.s * ox) * PS + 16 * half + j;
+    }
+  }
+  const float bias_a = (half == 0 && j == 0) ? 1.f : 0.f;     // the bias row's operand; the other rows of that tile are dead
+  f32x4 acc[5][NT];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[i][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  // Two loops with the same barriers, one per kind of wave (in one loop the registers of both kinds would be live
+  // together).  The filling waves request image n + 1 and write it within the iteration that multiplies image n; keeping
+  // a further image in registers across the barrier, or a second multiplying wave per SIMD (the pixel groups split in
+  // two, summed at the end), measured 95-97 us per 4096 images against 90 for this form.
+  if (filler) {
+    if (n0 < n1) { fetch(n0); stash(0); }
+    __syncthreads();
+    for (int n = n0; n < n1; ++n) {
+      if (n + 1 < n1) {
+        fetch(n + 1);
+        stash(((n - n0) & 1) ^ 1);                         // the other buffer: its last readers passed the previous barrier
+      }
+      __syncthreads();
+    }
+    return;
+  }
+  __syncthreads();
+  for (int n = n0; n < n1; ++n) {
+    const float* X = lds + ((n - n0) & 1) * BUF;
+    const float* xa[NG16][4];
+#pragma unroll
+    for (int G = 0; G < NG16; ++G) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) xa[G][e] = X + xo[G][e];
+    }
+    const float* Zq = X + HW * PS + (q * g.Cout + j) * 4;
+    if (set == 0) wgrad_img_products<0, NT, NG16, W, PS>(xa, Zq, g.Cout, bias_a, acc);
+    else wgrad_img_products<1, NT, NG16, W, PS>(xa, Zq, g.Cout, bias_a, acc);
+    __syncthreads();
+  }
+  const int NP = NT * 16;
+  float* out = slabs + (size_t)blockIdx.x * (g.NG * 16) * NP;
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const int rt = 2 * (2 * i + set) + half;             // 16 * rt = first patch element of the tile (tap * 32 + 16 * half); 18 = the bias row's tile
+    if (rt < g.NG) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[(16 * rt + 4 * q + r) * NP + 16 * nt + j] = acc[i][nt][r];
+      }
+    }
+  }
+}
+
 // grad[(k, n)] in canonical order ([K][Cout] kernel, then bias[Cout]) = sum of the slabs.  A workgroup
 // handles 16 entries; 16 threads per entry each add a strided share of the slabs in index order and the
 // 16 partial sums are added in a fixed order, so the result does not depend on timing.
@@ -1686,6 +1863,23 @@ int launch_wgrad(const ConvG& g, const S& src, const float* dz, const float* y_e
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)conv_wgrad_c4_kernel<2, XU, ZU, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((conv_wgrad_c4_kernel<2, XU, ZU, S>), dim3(used), dim3(256), lds, st, g, src, dz, y_elu, slabs, n_images, per);
       }
+      if (const int rc = launched()) return rc;
+      return reduce_slabs(slabs, used, g.NG * 16, g.NT * 16, g.K, g.Cout, grad, st);
+    }
+  }
+  static const bool no_img = getenv("RLGAN_NO_WGRAD_IMG") != nullptr;     // measurement switch
+  if (g.Cin == 32 && g.k == 3 && g.W == 20 && g.NT == 2 && g.Cout == 32 && g.NG == 19 && n_images >= 1024 && !no_img) {
+    // whole padded images in LDS, two buffers: four waves multiply while four fill
+    constexpr int NG16 = 6;                                   // up to 96 output pixels an image
+    const int HW = g.H * g.W, PP = NG16 * 16, PS = g.Cin + IMG_PAD;
+    const size_t lds = (size_t)2 * ((size_t)HW * PS + (size_t)PP * g.Cout) * sizeof(float);
+    if (cdiv(g.Ho * g.Wo, 16) == NG16 && lds <= 150 * 1024 && HW * (g.Cin / 4) <= IMG_FILL * 64 * IMG_XU &&
+        g.Ho * g.Wo * (g.Cout / 4) <= IMG_FILL * 64 * IMG_ZU) {
+      const int wgs = std::min(n_slabs, std::min(n_images, 256));
+      const int per = cdiv(n_images, wgs), used = cdiv(n_images, per);
+      hipStream_t st = (hipStream_t)stream;
+      (void)hipFuncSetAttribute((const void*)conv_wgrad_img_kernel<2, NG16, 20, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((conv_wgrad_img_kernel<2, NG16, 20, S>), dim3(used), dim3(IMG_WAVES * 64), lds, st, g, src, dz, y_elu, slabs, n_images, per);
       if (const int rc = launched()) return rc;
       return reduce_slabs(slabs, used, g.NG * 16, g.NT * 16, g.K, g.Cout, grad, st);
     }

@@ -245,6 +245,43 @@ def test_weight_gradient_two_ways(h, cin, cout, k, st, n):
         assert torch.equal(L.grad, got[ns])
 
 
+@pytest.mark.parametrize("n,ns", [(1024, 1024), (1100, 1024), (1500, 100)])
+def test_weight_gradient_of_the_32_channel_layer_with_images_in_lds(n, ns):
+    """From 1024 images on, the weight gradient of the 3x3 stride-2 layer with 32 input channels on 20x20 maps keeps whole
+    images in two LDS buffers (four waves multiply one while four fill the other): against the float64 restatement, with
+    as many workgroups as images allow (one to five images each) and with 100 slabs (15 images each, the last fewer), with
+    and without the ELU derivative, and the same bits on a second call."""
+    import rl_gan_amd as R
+    from gpu_util import close
+    from oracle import conv as oc
+    rng = np.random.RandomState(n)
+    L = R.ConvLayer(20, 20, 32, 32, 3, 2, rng=rng, bias_init=0.01)
+    x = torch.randn((n, 20, 20, 32), device="cuda")
+    y = L.forward(x)
+    dy = torch.randn_like(y)
+    w, b = L.kernel_bias()
+    w64 = w.astype(np.float64)
+    _, cache = oc.conv_forward(x.cpu().numpy().astype(np.float64), w64, b.astype(np.float64), 3, 2)
+    _, dw, db = oc.conv_backward(dy.cpu().numpy().astype(np.float64), w64, cache, 3, 2)
+    L.n_slabs, L._slabs = ns, None
+    L.grad.zero_()
+    L.backward(x, y, dy, need_dx=False)
+    first = L.grad.clone()
+    close(first.cpu().numpy(), np.concatenate([dw.ravel(), db.ravel()]), what="dW, images in LDS")
+    L.grad.zero_()
+    L.backward(x, y, dy, need_dx=False)
+    assert torch.equal(L.grad, first)
+    few = L.grad.clone()                                   # fewer than 1024 images take the other kernel: same sums, another order
+    L.grad.zero_()
+    L.backward(x[:1000].contiguous(), y[:1000].contiguous(), dy[:1000].contiguous(), need_dx=False)
+    assert not torch.equal(L.grad, few)
+    L.grad.zero_()
+    L.backward(x, y, dy, need_dx=False, act=False)         # no activation: dZ = dY
+    yl, cache = oc.conv_forward(x.cpu().numpy().astype(np.float64), w64, b.astype(np.float64), 3, 2, act=False)
+    _, dw, db = oc.conv_backward(dy.cpu().numpy().astype(np.float64), w64, cache, 3, 2, act=False)
+    close(L.grad.cpu().numpy(), np.concatenate([dw.ravel(), db.ravel()]), what="dW without the activation")
+
+
 @pytest.mark.parametrize("name", ["doom", "universe"])
 def test_first_layer_streamed_in_bands(name):
     """The first layer of the 84x84x4 encoders (5x5 stride 4 -> 8 channels, Conv_model.py:15-16; 3x3 stride 2 -> 32
