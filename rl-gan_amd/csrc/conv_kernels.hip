@@ -847,14 +847,25 @@ __global__ __launch_bounds__(256) void conv_dx_c4_lds_kernel(const ConvG g, cons
   const int n = blockIdx.x, npix = g.Ho * g.Wo;
   const f32x4* dz4 = (const f32x4*)(dz + (size_t)n * npix * CO);
   const f32x4* y4 = (const f32x4*)(yelu + (size_t)n * npix * CO);
-  for (int i = threadIdx.x; i < npix * C4; i += 256) {
-    f32x4 z = dz4[i];
-    if (yelu) {
-      const f32x4 y = y4[i];
-      z = f32x4{z[0] * elu_d(y[0]), z[1] * elu_d(y[1]), z[2] * elu_d(y[2]), z[3] * elu_d(y[3])};
+  // four pieces per thread and turn, their loads requested together (a piece per turn was a memory round trip per turn)
+  constexpr int SU = 4;
+  for (int i0 = threadIdx.x; i0 < npix * C4; i0 += 256 * SU) {
+    f32x4 zv[SU], yv[SU];
+#pragma unroll
+    for (int u = 0; u < SU; ++u) {
+      const int i = min(i0 + 256 * u, npix * C4 - 1);
+      zv[u] = dz4[i];
+      yv[u] = yelu ? y4[i] : f32x4{1.f, 1.f, 1.f, 1.f};
     }
-    float* zp = Z + (i / C4) * ZS + 4 * (i % C4);
-    zp[0] = z[0]; zp[1] = z[1]; zp[2] = z[2]; zp[3] = z[3];
+#pragma unroll
+    for (int u = 0; u < SU; ++u) {
+      const int i = i0 + 256 * u;
+      if (i < npix * C4) {
+        float* zp = Z + (i / C4) * ZS + 4 * (i % C4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) zp[c] = yelu ? zv[u][c] * elu_d(yv[u][c]) : zv[u][c];
+      }
+    }
   }
   __syncthreads();
   float* dxn = dx + (size_t)n * g.H * g.W * 4;

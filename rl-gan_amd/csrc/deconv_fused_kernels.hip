@@ -151,10 +151,21 @@ __global__ __launch_bounds__(256) void deconv_tile_dx_kernel(const float* __rest
   constexpr int C4 = T::CO / 4;
   const f32x4* dy4 = (const f32x4*)(dy + (size_t)n * T::NPIX * T::CO);
   const f32x4* y4 = (const f32x4*)(yact + (size_t)n * T::NPIX * T::CO);
-  for (int i = threadIdx.x; i < T::NPIX * C4; i += 256) {
-    f32x4 d = dy4[i];
-    if (yact) d = mask4(d, y4[i]);
-    *(f32x4*)(Z + (i / C4) * T::ZS + 4 * (i % C4)) = d;
+  // six pieces per thread and turn, their loads requested together (a piece per turn was a memory round trip per turn)
+  constexpr int SU = 6;
+  for (int i0 = threadIdx.x; i0 < T::NPIX * C4; i0 += 256 * SU) {
+    f32x4 d[SU], yv[SU];
+#pragma unroll
+    for (int u = 0; u < SU; ++u) {
+      const int i = min(i0 + 256 * u, T::NPIX * C4 - 1);
+      d[u] = dy4[i];
+      yv[u] = yact ? y4[i] : f32x4{1.f, 1.f, 1.f, 1.f};
+    }
+#pragma unroll
+    for (int u = 0; u < SU; ++u) {
+      const int i = i0 + 256 * u;
+      if (i < T::NPIX * C4) *(f32x4*)(Z + (i / C4) * T::ZS + 4 * (i % C4)) = yact ? mask4(d[u], yv[u]) : d[u];
+    }
   }
   __syncthreads();
   int ab[T::MT];
@@ -220,24 +231,49 @@ __global__ __launch_bounds__(256) void deconv_tile_dw_kernel(const float* __rest
     for (int c = 0; c < T::CT; ++c) acc[kx][c] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   constexpr int C4 = T::CO / 4;
-  for (int n = n0; n < n1; ++n) {
-    __syncthreads();                                       // the previous image's operands have been read
+  // An image's operands travel memory -> registers while the previous image is multiplied out of LDS, every piece of
+  // them requested at once (a piece per loop turn was a memory round trip per turn, nine per image, with nothing of the
+  // workgroup's own to cover them).
+  constexpr int XI = (T::P / 4) * T::CI, ZI = T::H * T::HO * C4, XU = (XI + 255) / 256, ZU = (ZI + 255) / 256;
+  f32x4 xr[XU], dr[ZU], yr[ZU];
+  auto fetch = [&](int n) {
     const float* xn = x + (size_t)n * T::P * T::CI;
-    for (int i = threadIdx.x; i < (T::P / 4) * T::CI; i += 256) {
-      const int pg = i / T::CI, ci = i % T::CI;
+#pragma unroll
+    for (int u = 0; u < XU; ++u) {
+      const int i = min((int)threadIdx.x + 256 * u, XI - 1), pg = i / T::CI, ci = i % T::CI;
       const float* xp = xn + (4 * pg) * T::CI + ci;
-      *(f32x4*)(Xt + i * 4) = f32x4{xp[0], xp[T::CI], xp[2 * T::CI], xp[3 * T::CI]};
+      xr[u] = f32x4{xp[0], xp[T::CI], xp[2 * T::CI], xp[3 * T::CI]};
     }
-    for (int i = threadIdx.x; i < T::H * T::HO * C4; i += 256) {
+#pragma unroll
+    for (int u = 0; u < ZU; ++u) {
+      const int i = min((int)threadIdx.x + 256 * u, ZI - 1);
       const int iy = i / (T::HO * C4), rem = i % (T::HO * C4), ox = rem / C4, c4 = rem % C4;
       const size_t at = (((size_t)n * T::HO + 2 * iy + ky) * T::HO + ox) * C4 + c4;
-      f32x4 d = ((const f32x4*)dy)[at];
-      if (yact) d = mask4(d, ((const f32x4*)yact)[at]);
-      float* z = Zr + iy * T::R + ox * T::S + 4 * c4;      // 8-byte aligned (S and R are even)
-      *(float2*)z = float2{d[0], d[1]};
-      *(float2*)(z + 2) = float2{d[2], d[3]};
+      dr[u] = ((const f32x4*)dy)[at];
+      yr[u] = yact ? ((const f32x4*)yact)[at] : f32x4{1.f, 1.f, 1.f, 1.f};
+    }
+  };
+  if (n0 < n1) fetch(n0);
+  for (int n = n0; n < n1; ++n) {
+    __syncthreads();                                       // the previous image's operands have been read
+#pragma unroll
+    for (int u = 0; u < XU; ++u) {
+      const int i = threadIdx.x + 256 * u;
+      if (i < XI) *(f32x4*)(Xt + i * 4) = xr[u];
+    }
+#pragma unroll
+    for (int u = 0; u < ZU; ++u) {
+      const int i = threadIdx.x + 256 * u;
+      if (i < ZI) {
+        const int iy = i / (T::HO * C4), rem = i % (T::HO * C4), ox = rem / C4, c4 = rem % C4;
+        const f32x4 d = yact ? mask4(dr[u], yr[u]) : dr[u];
+        float* z = Zr + iy * T::R + ox * T::S + 4 * c4;    // 8-byte aligned (S and R are even)
+        *(float2*)z = float2{d[0], d[1]};
+        *(float2*)(z + 2) = float2{d[2], d[3]};
+      }
     }
     __syncthreads();
+    if (n + 1 < n1) fetch(n + 1);
 #pragma unroll
     for (int G = 0; G < T::MT; ++G) {
       const f32x4 bx = *(const f32x4*)(Xt + ((4 * G + q) * T::CI + 16 * wave + j) * 4);
@@ -294,10 +330,21 @@ __global__ __launch_bounds__(256) void deconv_few_fwd_kernel(const float* __rest
   const int lane = threadIdx.x & 63, c = wave_id(), q = lane >> 4, j = lane & 15;
   const int n0 = blockIdx.x * 16;
   constexpr int ROW4 = T::P * T::CI / 4;                   // float4 per image
-  for (int i = threadIdx.x; i < 16 * ROW4; i += 256) {
-    const int r = i / ROW4, e = i - r * ROW4;
-    const int img = min(n0 + r, n_images - 1);             // rows past the last image repeat it; they are not stored
-    *(f32x4*)(lds + r * T::XS + 4 * e) = *(const f32x4*)(x + ((size_t)img * ROW4 + e) * 4);
+  // six pieces per thread and turn, their loads requested together (a piece per turn was a memory round trip per turn)
+  constexpr int SU = 6;
+  for (int i0 = threadIdx.x; i0 < 16 * ROW4; i0 += 256 * SU) {
+    f32x4 v[SU];
+#pragma unroll
+    for (int u = 0; u < SU; ++u) {
+      const int i = min(i0 + 256 * u, 16 * ROW4 - 1), r = i / ROW4, e = i - r * ROW4;
+      const int img = min(n0 + r, n_images - 1);           // rows past the last image repeat it; they are not stored
+      v[u] = *(const f32x4*)(x + ((size_t)img * ROW4 + e) * 4);
+    }
+#pragma unroll
+    for (int u = 0; u < SU; ++u) {
+      const int i = i0 + 256 * u, r = i / ROW4, e = i - r * ROW4;
+      if (i < 16 * ROW4) *(f32x4*)(lds + r * T::XS + 4 * e) = v[u];
+    }
   }
   __syncthreads();
   FragSrc ws;
@@ -462,23 +509,48 @@ __global__ __launch_bounds__(256) void deconv_narrow_bwd_kernel(const float* __r
 #pragma unroll
     for (int nt = 0; nt < N::NTC; ++nt) accw[tt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  for (int n = n0; n < n1; ++n) {
-    __syncthreads();
+  // An image's operands travel memory -> registers while the previous image is multiplied out of LDS, every piece of
+  // them requested at once (a piece per loop turn was a memory round trip per turn, eighteen per image).
+  constexpr int DU = (N::NO + 255) / 256, XI = (N::PP / 4) * N::CI, XU = (XI + 255) / 256;
+  float dreg[DU], yreg[DU];
+  f32x4 xreg[XU];
+  auto fetch = [&](int n) {
     const float* dyn = dy + (size_t)n * N::NO;
-    for (int o = threadIdx.x; o < N::NO; o += 256) {
-      float d = dyn[o];
-      if (yact) d *= relu_d(yact[(size_t)n * N::NO + o]);
-      Dimg[o] = d;
+#pragma unroll
+    for (int u = 0; u < DU; ++u) {
+      const int o = min((int)threadIdx.x + 256 * u, N::NO - 1);
+      dreg[u] = dyn[o];
+      yreg[u] = yact ? yact[(size_t)n * N::NO + o] : 1.f;
     }
     const float* xn = x + (size_t)n * N::P * N::CI;
-    for (int i = threadIdx.x; i < (N::PP / 4) * N::CI; i += 256) {
-      const int pg = i / N::CI, ci = i % N::CI;
-      f32x4 v;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = 4 * pg + e < N::P ? xn[(4 * pg + e) * N::CI + ci] : 0.f;
-      *(f32x4*)(Xt + i * 4) = v;
+    for (int u = 0; u < XU; ++u) {
+      const int i = min((int)threadIdx.x + 256 * u, XI - 1), pg = i / N::CI, ci = i % N::CI;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) xreg[u][e] = xn[min(4 * pg + e, N::P - 1) * N::CI + ci];
+    }
+  };
+  if (n0 < n1) fetch(n0);
+  for (int n = n0; n < n1; ++n) {
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < DU; ++u) {
+      const int o = threadIdx.x + 256 * u;
+      if (o < N::NO) Dimg[o] = yact ? dreg[u] * relu_d(yreg[u]) : dreg[u];
+    }
+#pragma unroll
+    for (int u = 0; u < XU; ++u) {
+      const int i = threadIdx.x + 256 * u;
+      if (i < XI) {
+        const int pg = i / N::CI;
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = 4 * pg + e < N::P ? xreg[u][e] : 0.f;
+        *(f32x4*)(Xt + i * 4) = v;
+      }
     }
     __syncthreads();
+    if (n + 1 < n1) fetch(n + 1);
     for (int t = wave; t < N::MT; t += 4) {
       if (DX) {
         const int pb = pixtab[16 * t + j];
