@@ -50,7 +50,7 @@ struct TileT {
   // an operand read (pixels 4 apart in x, or one input row apart) then start 16 banks apart.
   static constexpr int S = CO + 2, R = ((HO * S + 31) / 64) * 64 + 32;
   static constexpr int DW_LDS = (P * CI + H * R) * 4;
-  static constexpr int MAX_CHUNKS = 512;
+  static constexpr int MAX_CHUNKS = 256;
 };
 using Mid = TileT<8, 64, 32, 5>;
 
