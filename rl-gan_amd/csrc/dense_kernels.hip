@@ -11,6 +11,7 @@
 #include "rlgan_host.h"
 #include <algorithm>
 #include <cstdint>
+#include <type_traits>
 
 using namespace rlgan;
 
@@ -32,6 +33,7 @@ struct GemmArgs {
   int b_x, b_k;         // the same for B
   int ones_x, ones_k;   // A reads as 1 at this non-reduction (reduction) index; -1: none
   int act;              // epilogue: 1 = ELU, 2 = ReLU, 3 = relu6, 4 = tanh
+  int quads;            // every aligned group of four along the contiguous dimension of A and of B is inside or outside as a whole
   int k_split;          // reduction indices per blockIdx.y (a multiple of BK); with more than one split the
   size_t slab;          // raw partial products go to c + blockIdx.y * slab and split_sum_kernel finishes
 };
@@ -77,6 +79,30 @@ __device__ __forceinline__ void tile_load(f32x4 (&r)[TL], const float* __restric
     r[h] = v;
   }
 }
+// A border tile of an operand whose contiguous extent is a multiple of four (every layer width of the pixel networks):
+// an aligned group of four is inside or outside as a whole, so one 16-byte load from a clamped address and one
+// select per group do.  (With the element form a product paid for its border tiles with four times the loads and
+// twice the vector instructions per step: 4096 x 513 -> 500 ran 39 us against 30 us for -> 512.)
+template <bool KCONT>
+__device__ __forceinline__ void tile_load_quads(f32x4 (&r)[TL], const float* __restrict__ p, int ld, int x0, int k0, int nx, int nk,
+                                                int ones_x, int ones_k) {
+#pragma unroll
+  for (int h = 0; h < TL; ++h) {
+    const int u = threadIdx.x + 256 * h;
+    int x, k;
+    if (KCONT) { x = x0 + u / F4R; k = k0 + (u % F4R) * 4; }
+    else       { k = k0 + (u >> 4); x = x0 + (u & 15) * 4; }
+    const bool in = x < nx && k < nk;
+    f32x4 v = KCONT ? *(const f32x4*)(p + (size_t)min(x, nx - 1) * ld + min(k, nk - 4))
+                    : *(const f32x4*)(p + (size_t)min(k, nk - 1) * ld + min(x, nx - 4));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (!in) v[i] = 0.f;
+      if (KCONT ? (k + i == ones_k || x == ones_x) : (x + i == ones_x || k == ones_k)) v[i] = 1.f;
+    }
+    r[h] = v;
+  }
+}
 // The same for a tile that lies wholly inside the operand and holds no ones index: no per-lane condition.
 // (Conditions around the loads make the wave wait for them where the branches join, i.e. before the
 // multiplications they are meant to overlap with; the main loop below therefore runs on this form alone.)
@@ -117,9 +143,18 @@ __device__ __forceinline__ void tile_store(float* t, const f32x4 (&r)[TL]) {
 template <bool A_KCONT, bool B_KCONT>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];           // 4 * TILE_FLOATS: A and B tiles, two stages
-  // consecutive workgroups share the A tile (same rows, neighbouring column tiles)
+  // Workgroups go to the eight XCDs in turn, each with an L2 of its own: workgroup f of the launch takes the f/8-th
+  // of the run of (tile, slab) pairs that belongs to XCD f%8, so that the column tiles that share the rows of A, and
+  // the row tiles that share a slab of B, meet in one L2.
+#ifndef RLGAN_GEMM_NO_XCD
+  const unsigned flat = blockIdx.y * gridDim.x + blockIdx.x, total = gridDim.x * gridDim.y;
+  const unsigned xcd = flat & 7, pair = xcd * (total >> 3) + min(xcd, total & 7) + (flat >> 3);
+  const int tile = (int)(pair % gridDim.x), zi = (int)(pair / gridDim.x);
+#else
+  const int tile = (int)blockIdx.x, zi = (int)blockIdx.y;
+#endif
   const int ntn = cdiv(g.N, BN);
-  const int m0 = ((int)blockIdx.x / ntn) * BM, n0 = ((int)blockIdx.x % ntn) * BN;
+  const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
   const int lane = threadIdx.x & 63, wave = wave_id();
   const int q4 = (lane >> 4) * 4, j = lane & 15;
   const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
@@ -131,9 +166,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
 #pragma unroll
     for (int t = 0; t < 2; ++t) acc[s][t] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  const int kb = (int)blockIdx.y * g.k_split;                       // this split's reduction range
+  const int kb = zi * g.k_split;                                    // this slab's reduction range
   const int nkt = cdiv(min(g.K - kb, g.k_split), BK);
-  float* cz = g.c + (size_t)blockIdx.y * g.slab;
+  float* cz = g.c + (size_t)zi * g.slab;
   // leading reduction steps whose A and B tiles lie wholly inside the operands (no edge, no ones index)
   int nin = 0;
   if (m0 + BM <= ax && n0 + BN <= g.b_x && (g.ones_x < m0 || g.ones_x >= m0 + BM)) {
@@ -141,15 +176,21 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
     if (g.ones_k >= 0) kin = min(kin, g.ones_k);
     nin = max(0, min(nkt, (kin - kb) / BK));
   }
-  auto load = [&](int kt, bool inside) {
-    if (inside) {
+  // mode 0: inside, 1: border by groups of four, 2: border by elements.  The mode is chosen outside the loops: a
+  // branch between the loads and the products would make the wave wait for the loads where its arms join.
+  auto load = [&](int kt, auto mode) {
+    if constexpr (mode.value == 0) {
       tile_load_inside<A_KCONT>(ra, g.a, g.lda, m0, kb + kt * BK);
       tile_load_inside<B_KCONT>(rb, g.b, g.ldb, n0, kb + kt * BK);
+    } else if constexpr (mode.value == 1) {
+      tile_load_quads<A_KCONT>(ra, g.a, g.lda, m0, kb + kt * BK, ax, ak, g.ones_x, g.ones_k);
+      tile_load_quads<B_KCONT>(rb, g.b, g.ldb, n0, kb + kt * BK, g.b_x, g.b_k, -1, -1);
     } else {
       tile_load<A_KCONT>(ra, g.a, g.lda, m0, kb + kt * BK, ax, ak, g.ones_x, g.ones_k);
       tile_load<B_KCONT>(rb, g.b, g.ldb, n0, kb + kt * BK, g.b_x, g.b_k, -1, -1);
     }
   };
+  using Inside = std::integral_constant<int, 0>; using Quads = std::integral_constant<int, 1>; using Elements = std::integral_constant<int, 2>;
   auto multiply = [&](int kt) {
     const float* as = lds + (kt & 1) * 2 * TILE_FLOATS;
     const float* bs = as + TILE_FLOATS;
@@ -176,26 +217,32 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
     tile_store<A_KCONT>(an, ra);
     tile_store<B_KCONT>(an + TILE_FLOATS, rb);
   };
-  load(0, nin > 0);
+  if (nin > 0) load(0, Inside{});
+  else if (g.quads) load(0, Quads{});
+  else load(0, Elements{});
   stash(0);
   __syncthreads();
   int kt = 0;
   for (; kt + 1 < nin; ++kt) {          // the bulk: the next step's tiles are inside, nothing but loads, products, stores
-    load(kt + 1, true);
+    load(kt + 1, Inside{});
     __builtin_amdgcn_sched_barrier(0);  // keep the fetches ahead of the products (the scheduler would sink them to their use)
     multiply(kt);
     __builtin_amdgcn_sched_barrier(0);
     stash(kt + 1);
     __syncthreads();
   }
-  for (; kt < nkt; ++kt) {              // the edge steps (and everything, for a tile on the operands' border): same pipeline
-    if (kt + 1 < nkt) load(kt + 1, false);
-    __builtin_amdgcn_sched_barrier(0);
-    multiply(kt);
-    __builtin_amdgcn_sched_barrier(0);
-    if (kt + 1 < nkt) stash(kt + 1);
-    __syncthreads();
-  }
+  auto edge = [&](auto mode) {          // the edge steps (and everything, for a tile on the operands' border): same pipeline
+    for (; kt < nkt; ++kt) {
+      if (kt + 1 < nkt) load(kt + 1, mode);
+      __builtin_amdgcn_sched_barrier(0);
+      multiply(kt);
+      __builtin_amdgcn_sched_barrier(0);
+      if (kt + 1 < nkt) stash(kt + 1);
+      __syncthreads();
+    }
+  };
+  if (g.quads) edge(Quads{});
+  else edge(Elements{});
   // lane (q, j) of an accumulator tile holds rows 4q..4q+3 of column j
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
@@ -254,6 +301,7 @@ int launch_gemm(GemmArgs g, float* slabs, int n_slabs, void* stream) {
   const long long blocks = (long long)cdiv(g.M, BM) * cdiv(g.N, BN);
   if (blocks > 0x7fffffffll) return RLGAN_E_ARG;
   g.k_split = g.K; g.slab = 0;
+  g.quads = (A_KCONT ? g.a_k : g.a_x) % 4 == 0 && (B_KCONT ? g.b_k : g.b_x) % 4 == 0;
   constexpr size_t GEMM_LDS = (size_t)4 * TILE_FLOATS * sizeof(float);
   if (GEMM_LDS > 64 * 1024) (void)hipFuncSetAttribute((const void*)gemm_kernel<A_KCONT, B_KCONT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS);
   int nz = 1;

@@ -125,6 +125,30 @@ def test_dense_kernel_gradient_without_the_bias_row(m, k, n, ns):
     assert _lib.lib.rlgan_dense_backward_kernel(xt.data_ptr(), k - 1, dzt.data_ptr(), n, gw.data_ptr(), m, k, n, None, 1, None) == -1
 
 
+@pytest.mark.parametrize("m,k,ldx,n", [(70, 18, 20, 12), (130, 201, 204, 72), (64, 66, 68, 500)])
+def test_dense_products_with_a_width_that_is_not_a_multiple_of_four(m, k, ldx, n):
+    """Rows of x padded to a multiple of four floats with k itself odd-sized: border tiles are then read element by
+    element instead of in aligned groups of four; forward and weight gradient against float64, padding never read as data."""
+    from rl_gan_amd import _lib
+    from gpu_util import close
+    rng = np.random.RandomState(k + n)
+    x = np.full((m, ldx), np.nan, np.float32)
+    x[:, :k] = rng.standard_normal((m, k))
+    wb = (rng.uniform(-1, 1, (k + 1, n)) * 0.2).astype(np.float32)
+    dz = rng.standard_normal((m, n)).astype(np.float32)
+    xt, wbt, dzt = (torch.from_numpy(a).cuda() for a in (x, wb, dz))
+    y = torch.empty((m, n), device="cuda")
+    assert _lib.lib.rlgan_dense_forward(xt.data_ptr(), ldx, wbt.data_ptr(), y.data_ptr(), n, m, k, n, 0, None, 1, None) == 0
+    x64 = x[:, :k].astype(np.float64)
+    close(y.cpu().numpy(), x64 @ wb[:k].astype(np.float64) + wb[k].astype(np.float64), what="forward, odd k")
+    gwb = torch.empty((k + 1, n), device="cuda")
+    slabs = torch.empty(2 * (k + 1) * n, device="cuda")
+    assert _lib.lib.rlgan_dense_backward_weights(xt.data_ptr(), ldx, dzt.data_ptr(), n, gwb.data_ptr(), m, k, n, slabs.data_ptr(), 2, None) == 0
+    g = gwb.cpu().numpy()
+    close(g[:k], x64.T @ dz.astype(np.float64), what="dW, odd k")
+    close(g[k], dz.astype(np.float64).sum(0), what="db, odd k")
+
+
 def test_encoder_with_dense_head_end_to_end():
     """doom head + fc(256): features, and the gradient reaching the first conv layer."""
     import rl_gan_amd as R
