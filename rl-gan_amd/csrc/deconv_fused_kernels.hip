@@ -54,50 +54,35 @@ struct TileT {
 };
 using Mid = TileT<8, 64, 32, 5>;
 
-// y[n] = act(bias + sum over taps of place(X[n] W_tap)).  grid = ceil(n / IPW); wave = (image, channel tile).
-template <class T>
-__global__ __launch_bounds__(256) void deconv_tile_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wff,
-                                                               const float* __restrict__ bias, float* __restrict__ y,
-                                                               int n_images, int act) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int lane = threadIdx.x & 63, wave = wave_id(), q = lane >> 4, j = lane & 15;
-  const int c = wave % T::CT, n = blockIdx.x * T::IPW + wave / T::CT;
-  if (n >= n_images) return;                               // the waves of this kernel never meet at a barrier
-  float* Y = lds + wave * (T::NPIX * 16);
-  FragSrc ws;
-  ws.set(wff, c * T::KG);
+// The taps of a stride-2 layer fall into classes by the parity of (ky, kx), and the classes write disjoint output
+// pixels (oy = 2 iy + ky).  Side 0 of a pair of waves takes the taps with ky + kx even, side 1 the others (13 and 12
+// of the 25 taps of a 5x5 kernel): the two add into one output tile at the same time without ever meeting in an
+// element, and every element still receives its taps in ascending order.
+template <class T> __host__ __device__ constexpr int tile_side_taps(int side) {
+  int n = 0;
+  for (int tap = 0; tap < T::TAPS; ++tap) n += ((tap / T::K + tap % T::K) & 1) == side;
+  return n;
+}
+template <class T> __host__ __device__ constexpr int tile_side_tap(int side, int i) {
+  for (int tap = 0; tap < T::TAPS; ++tap) {
+    if (((tap / T::K + tap % T::K) & 1) == side && i-- == 0) return tap;
+  }
+  return T::TAPS;
+}
+template <class T, int SIDE>
+__device__ __forceinline__ void tile_fwd_taps(const f32x4 (&a)[T::MT][T::KG], float* Y, const int (&po)[T::MT][4], const FragSrc& ws) {
+  constexpr int N = tile_side_taps<T>(SIDE);
   f32x4 b[2][T::KG];
 #pragma unroll
-  for (int g = 0; g < T::KG; ++g) b[0][g] = ws.load(g);
-  // the image's input pixels as A operands, kept for all taps
-  f32x4 a[T::MT][T::KG];
-  const float* xn = x + (size_t)n * T::P * T::CI;
-#pragma unroll
-  for (int t = 0; t < T::MT; ++t) {
-#pragma unroll
-    for (int g = 0; g < T::KG; ++g) a[t][g] = *(const f32x4*)(xn + (16 * t + j) * T::CI + 16 * g + 4 * q);
-  }
-  const f32x4 b4 = *(const f32x4*)(bias + 16 * c + 4 * (lane & 3));
-  for (int i = lane; i < T::NPIX * 4; i += 64) ((f32x4*)Y)[i] = b4;
-  keep_lds_order();
-  // LDS position of accumulator element (t, r) = input pixel 16 t + 4 q + r, channel j, for tap (0, 0)
-  int po[T::MT][4];
-#pragma unroll
-  for (int t = 0; t < T::MT; ++t) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int px = 16 * t + 4 * q + r;
-      po[t][r] = ((2 * (px / T::H)) * T::HO + 2 * (px % T::H)) * 16 + j;
-    }
-  }
+  for (int g = 0; g < T::KG; ++g) b[0][g] = ws.load(tile_side_tap<T>(SIDE, 0) * T::CT * T::KG + g);
   f32x4 prev[T::MT];
 #pragma unroll
-  for (int tap = 0; tap <= T::TAPS; ++tap) {
+  for (int i = 0; i <= N; ++i) {
     f32x4 acc[T::MT];
-    if (tap < T::TAPS) {
-      if (tap + 1 < T::TAPS) {
+    if (i < N) {
+      if (i + 1 < N) {
 #pragma unroll
-        for (int g = 0; g < T::KG; ++g) b[(tap + 1) & 1][g] = ws.load((tap + 1) * T::CT * T::KG + g);
+        for (int g = 0; g < T::KG; ++g) b[(i + 1) & 1][g] = ws.load(tile_side_tap<T>(SIDE, i + 1) * T::CT * T::KG + g);
       }
 #pragma unroll
       for (int t = 0; t < T::MT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -106,13 +91,14 @@ __global__ __launch_bounds__(256) void deconv_tile_fwd_kernel(const float* __res
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
 #pragma unroll
-          for (int t = 0; t < T::MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][g][m], b[tap & 1][g][m], acc[t], 0, 0, 0);
+          for (int t = 0; t < T::MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][g][m], b[i & 1][g][m], acc[t], 0, 0, 0);
         }
       }
     }
-    if (tap > 0) {
+    if (i > 0) {
       // the previous tap's products go to their output pixels while this tap's MFMAs run
-      const int off = (((tap - 1) / T::K) * T::HO + (tap - 1) % T::K) * 16;
+      const int tap = tile_side_tap<T>(SIDE, i - 1);
+      const int off = ((tap / T::K) * T::HO + tap % T::K) * 16;
 #pragma unroll
       for (int t = 0; t < T::MT; ++t) {
 #pragma unroll
@@ -123,8 +109,51 @@ __global__ __launch_bounds__(256) void deconv_tile_fwd_kernel(const float* __res
 #pragma unroll
     for (int t = 0; t < T::MT; ++t) prev[t] = acc[t];
   }
+}
+
+// y[n] = act(bias + sum over taps of place(X[n] W_tap)).  grid = ceil(n / IPW); eight waves: waves w and w + 4 (one
+// SIMD) are the two sides of (image, channel tile) w, so each SIMD has one wave's additions into LDS, its first
+// loads and its last stores to run under the other's products.  (With one wave per tile, all taps in a row, the
+// matrix pipe stood idle for 15 of the 40 us a workgroup took.)
+template <class T>
+__global__ __launch_bounds__(512) void deconv_tile_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wff,
+                                                               const float* __restrict__ bias, float* __restrict__ y,
+                                                               int n_images, int act) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lane = threadIdx.x & 63, wave = wave_id(), q = lane >> 4, j = lane & 15;
+  const int tile = wave & 3, side = wave >> 2;
+  const int c = tile % T::CT, n = blockIdx.x * T::IPW + tile / T::CT;
+  const bool live = n < n_images;                          // a tile past the last image computes the last image again and stores nothing
+  float* Y = lds + tile * (T::NPIX * 16);
+  FragSrc ws;
+  ws.set(wff, c * T::KG);
+  // the image's input pixels as A operands, kept for all taps
+  f32x4 a[T::MT][T::KG];
+  const float* xn = x + (size_t)min(n, n_images - 1) * T::P * T::CI;
+#pragma unroll
+  for (int t = 0; t < T::MT; ++t) {
+#pragma unroll
+    for (int g = 0; g < T::KG; ++g) a[t][g] = *(const f32x4*)(xn + (16 * t + j) * T::CI + 16 * g + 4 * q);
+  }
+  const f32x4 b4 = *(const f32x4*)(bias + 16 * c + 4 * (lane & 3));
+  for (int i = lane + 64 * side; i < T::NPIX * 4; i += 128) ((f32x4*)Y)[i] = b4;
+  // LDS position of accumulator element (t, r) = input pixel 16 t + 4 q + r, channel j, for tap (0, 0)
+  int po[T::MT][4];
+#pragma unroll
+  for (int t = 0; t < T::MT; ++t) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int px = 16 * t + 4 * q + r;
+      po[t][r] = ((2 * (px / T::H)) * T::HO + 2 * (px % T::H)) * 16 + j;
+    }
+  }
+  __syncthreads();                                         // both sides' halves of the bias are in place
+  if (side == 0) tile_fwd_taps<T, 0>(a, Y, po, ws);
+  else tile_fwd_taps<T, 1>(a, Y, po, ws);
+  __syncthreads();
+  if (!live) return;
   float* yn = y + (size_t)n * T::NPIX * T::CO + 16 * c + 4 * (lane & 3);
-  for (int i = lane; i < T::NPIX * 4; i += 64) {
+  for (int i = lane + 64 * side; i < T::NPIX * 4; i += 128) {
     f32x4 v = ((const f32x4*)Y)[i];
     if (act) v = f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
     *(f32x4*)(yn + (size_t)(i >> 2) * T::CO) = v;
@@ -717,7 +746,7 @@ int rlgan_deconv_fused_forward(const rlgan_deconv_t* d, const float* x, const fl
   if (((uintptr_t)x | (uintptr_t)wff | (uintptr_t)bias | (uintptr_t)y) & 15) return RLGAN_E_ALIGN;
   if (kind == FUSED_TILE) {
     allow_lds(deconv_tile_fwd_kernel<Mid>, Mid::FWD_LDS);
-    hipLaunchKernelGGL(deconv_tile_fwd_kernel<Mid>, dim3(cdiv(n_images, Mid::IPW)), dim3(256), Mid::FWD_LDS, (hipStream_t)stream,
+    hipLaunchKernelGGL(deconv_tile_fwd_kernel<Mid>, dim3(cdiv(n_images, Mid::IPW)), dim3(512), Mid::FWD_LDS, (hipStream_t)stream,
                        x, wff, bias, y, n_images, act_relu);
   } else if (kind == FUSED_FEW_FWD) {
     allow_lds(deconv_few_fwd_kernel<Few>, Few::FWD_LDS);
