@@ -58,14 +58,25 @@ using Mid = TileT<8, 64, 32, 5>;
 // pixels (oy = 2 iy + ky).  Side 0 of a pair of waves takes the taps with ky + kx even, side 1 the others (13 and 12
 // of the 25 taps of a 5x5 kernel): the two add into one output tile at the same time without ever meeting in an
 // element, and every element still receives its taps in ascending order.
+// (Three sides -- the classes as 9, 6 + 4 and 6 taps, three waves per SIMD -- measured no faster than two: 261 against 259 us.)
+#ifndef RLGAN_TILE_SIDES
+#define RLGAN_TILE_SIDES 2
+#endif
+constexpr int TILE_SIDES = RLGAN_TILE_SIDES;
+template <class T> __host__ __device__ constexpr int tile_side_of(int tap) {
+  const int ky = tap / T::K, kx = tap % T::K;
+  if (TILE_SIDES == 2) return (ky + kx) & 1;
+  const int cls = (ky & 1) * 2 + (kx & 1);
+  return cls == 0 ? 0 : cls == 2 ? 2 : 1;
+}
 template <class T> __host__ __device__ constexpr int tile_side_taps(int side) {
   int n = 0;
-  for (int tap = 0; tap < T::TAPS; ++tap) n += ((tap / T::K + tap % T::K) & 1) == side;
+  for (int tap = 0; tap < T::TAPS; ++tap) n += tile_side_of<T>(tap) == side;
   return n;
 }
 template <class T> __host__ __device__ constexpr int tile_side_tap(int side, int i) {
   for (int tap = 0; tap < T::TAPS; ++tap) {
-    if (((tap / T::K + tap % T::K) & 1) == side && i-- == 0) return tap;
+    if (tile_side_of<T>(tap) == side && i-- == 0) return tap;
   }
   return T::TAPS;
 }
@@ -116,7 +127,7 @@ __device__ __forceinline__ void tile_fwd_taps(const f32x4 (&a)[T::MT][T::KG], fl
 // loads and its last stores to run under the other's products.  (With one wave per tile, all taps in a row, the
 // matrix pipe stood idle for 15 of the 40 us a workgroup took.)
 template <class T>
-__global__ __launch_bounds__(512) void deconv_tile_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wff,
+__global__ __launch_bounds__(256 * TILE_SIDES) void deconv_tile_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wff,
                                                                const float* __restrict__ bias, float* __restrict__ y,
                                                                int n_images, int act) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -136,7 +147,7 @@ __global__ __launch_bounds__(512) void deconv_tile_fwd_kernel(const float* __res
     for (int g = 0; g < T::KG; ++g) a[t][g] = *(const f32x4*)(xn + (16 * t + j) * T::CI + 16 * g + 4 * q);
   }
   const f32x4 b4 = *(const f32x4*)(bias + 16 * c + 4 * (lane & 3));
-  for (int i = lane + 64 * side; i < T::NPIX * 4; i += 128) ((f32x4*)Y)[i] = b4;
+  for (int i = lane + 64 * side; i < T::NPIX * 4; i += 64 * TILE_SIDES) ((f32x4*)Y)[i] = b4;
   // LDS position of accumulator element (t, r) = input pixel 16 t + 4 q + r, channel j, for tap (0, 0)
   int po[T::MT][4];
 #pragma unroll
@@ -149,11 +160,12 @@ __global__ __launch_bounds__(512) void deconv_tile_fwd_kernel(const float* __res
   }
   __syncthreads();                                         // both sides' halves of the bias are in place
   if (side == 0) tile_fwd_taps<T, 0>(a, Y, po, ws);
-  else tile_fwd_taps<T, 1>(a, Y, po, ws);
+  else if (side == 1) tile_fwd_taps<T, 1>(a, Y, po, ws);
+  else tile_fwd_taps<T, TILE_SIDES - 1>(a, Y, po, ws);
   __syncthreads();
   if (!live) return;
   float* yn = y + (size_t)n * T::NPIX * T::CO + 16 * c + 4 * (lane & 3);
-  for (int i = lane + 64 * side; i < T::NPIX * 4; i += 128) {
+  for (int i = lane + 64 * side; i < T::NPIX * 4; i += 64 * TILE_SIDES) {
     f32x4 v = ((const f32x4*)Y)[i];
     if (act) v = f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
     *(f32x4*)(yn + (size_t)(i >> 2) * T::CO) = v;
@@ -746,7 +758,7 @@ int rlgan_deconv_fused_forward(const rlgan_deconv_t* d, const float* x, const fl
   if (((uintptr_t)x | (uintptr_t)wff | (uintptr_t)bias | (uintptr_t)y) & 15) return RLGAN_E_ALIGN;
   if (kind == FUSED_TILE) {
     allow_lds(deconv_tile_fwd_kernel<Mid>, Mid::FWD_LDS);
-    hipLaunchKernelGGL(deconv_tile_fwd_kernel<Mid>, dim3(cdiv(n_images, Mid::IPW)), dim3(512), Mid::FWD_LDS, (hipStream_t)stream,
+    hipLaunchKernelGGL(deconv_tile_fwd_kernel<Mid>, dim3(cdiv(n_images, Mid::IPW)), dim3(256 * TILE_SIDES), Mid::FWD_LDS, (hipStream_t)stream,
                        x, wff, bias, y, n_images, act_relu);
   } else if (kind == FUSED_FEW_FWD) {
     allow_lds(deconv_few_fwd_kernel<Few>, Few::FWD_LDS);
