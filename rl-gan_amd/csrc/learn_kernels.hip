@@ -657,7 +657,14 @@ __global__ __launch_bounds__(256) void apply_kernel(const ApplyArgs A) {
 __global__ void sum_parts_kernel(const float* __restrict__ parts, int n_parts, float scale, float* __restrict__ out) {
   const float* p = parts + (size_t)blockIdx.x * n_parts;
   float s = 0.f;
-  for (int i = threadIdx.x; i < n_parts; i += 64) s += p[i];
+  constexpr int FL = 16;                                  // loads in flight per lane and turn (one per turn: a memory round trip per addition)
+  for (int i0 = threadIdx.x; i0 < n_parts; i0 += 64 * FL) {
+    float v[FL];
+#pragma unroll
+    for (int u = 0; u < FL; ++u) v[u] = p[min(i0 + 64 * u, n_parts - 1)];
+#pragma unroll
+    for (int u = 0; u < FL; ++u) s += i0 + 64 * u < n_parts ? v[u] : 0.f;
+  }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
   if (threadIdx.x == 0) out[blockIdx.x] = s * scale;
