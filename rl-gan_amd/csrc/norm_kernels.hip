@@ -109,9 +109,19 @@ __global__ __launch_bounds__(256) void bn_chunk_stats_kernel(const float* __rest
 // chunk statistics joined in chunk order (pairwise update of count, mean and sum of squared deviations)
 __global__ void bn_join_stats_kernel(const float* __restrict__ scratch, int m, int n, int rows, int chunks, float eps,
                                      float* __restrict__ save_mean, float* __restrict__ save_inv_std) {
+  // The two weights of a chunk's update depend on its position alone (rows before it and in it; the counts are whole
+  // numbers below 2^24, which a float sum holds exactly): the lanes work them out side by side, two divisions per
+  // chunk in all, instead of every column repeating them inside its chain of updates.
+  __shared__ float w_mean[BN_MAX_CHUNKS], w_m2[BN_MAX_CHUNKS];
+  for (int k = threadIdx.x; k < chunks; k += blockDim.x) {
+    const float cnt = (float)(k * rows), nb = (float)(min(m, (k + 1) * rows) - k * rows), tot = cnt + nb;
+    w_mean[k] = nb / tot;
+    w_m2[k] = cnt * nb / tot;
+  }
+  __syncthreads();
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= n) return;
-  float cnt = 0.f, mean = 0.f, m2 = 0.f;
+  float mean = 0.f, m2 = 0.f;
   constexpr int FL = 32;                                 // chunks whose loads are in flight together, then the dependent updates
   for (int k0 = 0; k0 < chunks; k0 += FL) {              // (eight at a time: sixteen memory round trips for 128 chunks, 18 us)
     float mb[FL], qb[FL];
@@ -124,11 +134,9 @@ __global__ void bn_join_stats_kernel(const float* __restrict__ scratch, int m, i
     for (int j = 0; j < FL; ++j) {
       const int k = k0 + j;
       if (k < chunks) {
-        const float nb = (float)(min(m, (k + 1) * rows) - k * rows);
-        const float tot = cnt + nb, delta = mb[j] - mean;
-        mean += delta * (nb / tot);
-        m2 += qb[j] + delta * delta * (cnt * nb / tot);
-        cnt = tot;
+        const float delta = mb[j] - mean;
+        mean += delta * w_mean[k];
+        m2 += qb[j] + delta * delta * w_m2[k];
       }
     }
   }
