@@ -363,27 +363,81 @@ struct FewT {
 };
 using Few = FewT<3, 128, 64, 4>;
 
+// One stride phase of sixteen images for one wave: the grid rows 2 HALF and 2 HALF + 1 of the phase's 4x4 grid of output
+// pixels.  Every (input pixel, tap) pair feeds exactly one grid point, so the two halves share no accumulator, each
+// gets half of the pairs (18 of 36), and a grid point still receives its taps in ascending order.
+template <class T, int HALF>
+__device__ __forceinline__ void few_fwd_half(const float* xa, const FragSrc& ws, float bj, int ph, float* __restrict__ y, int n0,
+                                             int n_images, int c, int act) {
+  const int lane = threadIdx.x & 63, q = lane >> 4, j = lane & 15;
+  const int ry = ph >> 1, rx = ph & 1;
+  constexpr int HR = T::GA / 2;                            // grid rows per half
+  f32x4 acc[HR * T::GA];
+#pragma unroll
+  for (int i = 0; i < HR * T::GA; ++i) acc[i] = f32x4{bj, bj, bj, bj};
+  // one set of kernel fragments: a k-group's fragment of the next tap is requested as soon as the group's products of
+  // this tap are issued, and has the other groups' products to arrive under
+  f32x4 b[T::KG];
+#pragma unroll
+  for (int g = 0; g < T::KG; ++g) b[g] = ws.load(((ry * T::K + rx) * T::CT) * T::KG + g);
+#pragma unroll
+  for (int uv = 0; uv < (T::K / 2) * (T::K / 2); ++uv) {
+    const int u = uv / (T::K / 2), v = uv % (T::K / 2);
+    const int un = (uv + 1) / (T::K / 2), vn = (uv + 1) % (T::K / 2);
+    const int tapn = (ry + 2 * un) * T::K + rx + 2 * vn;
+#pragma unroll
+    for (int g = 0; g < T::KG; ++g) {
+      keep_lds_order();                                    // the inputs are read again for every tap: kept across taps they would spill
+#pragma unroll
+      for (int p = 0; p < T::P; ++p) {
+        const int row = p / T::H + u;
+        if (row / HR != HALF) continue;
+        const int pos = (row - HALF * HR) * T::GA + p % T::H + v;
+        const f32x4 a = *(const f32x4*)(xa + p * T::CI + 16 * g);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[pos] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], b[g][m], acc[pos], 0, 0, 0);
+      }
+      if (uv + 1 < (T::K / 2) * (T::K / 2)) b[g] = ws.load((tapn * T::CT) * T::KG + g);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < HR * T::GA; ++i) {
+    const int oy = 2 * (i / T::GA + HALF * HR) + ry, ox = 2 * (i % T::GA) + rx;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int img = n0 + 4 * q + r;
+      if (img < n_images) {
+        const float v = acc[i][r];
+        y[((size_t)img * T::NPIX + oy * T::HO + ox) * T::CO + 16 * c + j] = act ? fmaxf(v, 0.f) : v;
+      }
+    }
+  }
+}
+
+// grid = (ceil(n / 16), 4 stride phases); eight waves: a 16-channel output tile and one half of the phase's grid rows each.
+// One stride phase per workgroup: at a batch of 32 the layer is two image tiles, and with all four phases in one
+// workgroup it took 108 us at any batch size (a chain of 4608 products per wave).
 template <class T>
-__global__ __launch_bounds__(256) void deconv_few_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wff,
+__global__ __launch_bounds__(512, 4) void deconv_few_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wff,
                                                               const float* __restrict__ bias, float* __restrict__ y,
                                                               int n_images, int act) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int lane = threadIdx.x & 63, c = wave_id(), q = lane >> 4, j = lane & 15;
+  const int lane = threadIdx.x & 63, wave = wave_id(), c = wave & 3, half = wave >> 2, q = lane >> 4, j = lane & 15;
   const int n0 = blockIdx.x * 16;
   constexpr int ROW4 = T::P * T::CI / 4;                   // float4 per image
-  // six pieces per thread and turn, their loads requested together (a piece per turn was a memory round trip per turn)
-  constexpr int SU = 6;
-  for (int i0 = threadIdx.x; i0 < 16 * ROW4; i0 += 256 * SU) {
+  // all pieces of a thread requested together (a piece per turn was a memory round trip per turn)
+  constexpr int SU = (16 * ROW4 + 511) / 512;
+  {
     f32x4 v[SU];
 #pragma unroll
     for (int u = 0; u < SU; ++u) {
-      const int i = min(i0 + 256 * u, 16 * ROW4 - 1), r = i / ROW4, e = i - r * ROW4;
+      const int i = min((int)threadIdx.x + 512 * u, 16 * ROW4 - 1), r = i / ROW4, e = i - r * ROW4;
       const int img = min(n0 + r, n_images - 1);           // rows past the last image repeat it; they are not stored
       v[u] = *(const f32x4*)(x + ((size_t)img * ROW4 + e) * 4);
     }
 #pragma unroll
     for (int u = 0; u < SU; ++u) {
-      const int i = i0 + 256 * u, r = i / ROW4, e = i - r * ROW4;
+      const int i = threadIdx.x + 512 * u, r = i / ROW4, e = i - r * ROW4;
       if (i < 16 * ROW4) *(f32x4*)(lds + r * T::XS + 4 * e) = v[u];
     }
   }
@@ -392,50 +446,8 @@ __global__ __launch_bounds__(256) void deconv_few_fwd_kernel(const float* __rest
   ws.set(wff, c * T::KG);
   const float bj = bias[16 * c + j];
   const float* xa = lds + j * T::XS + 4 * q;
-  // one stride phase per workgroup (blockIdx.y): four times the workgroups -- at a batch of 32 the layer is two image
-  // tiles, and with all four phases in one workgroup it took 108 us at any batch size (a chain of 4608 products per wave)
-  {
-    const int ph = blockIdx.y;
-    const int ry = ph >> 1, rx = ph & 1;
-    f32x4 acc[T::GA * T::GA];
-#pragma unroll
-    for (int i = 0; i < T::GA * T::GA; ++i) acc[i] = f32x4{bj, bj, bj, bj};
-    f32x4 b[2][T::KG];
-#pragma unroll
-    for (int g = 0; g < T::KG; ++g) b[0][g] = ws.load(((ry * T::K + rx) * T::CT) * T::KG + g);
-#pragma unroll
-    for (int uv = 0; uv < (T::K / 2) * (T::K / 2); ++uv) {
-      const int u = uv / (T::K / 2), v = uv % (T::K / 2);
-      if (uv + 1 < (T::K / 2) * (T::K / 2)) {
-        const int un = (uv + 1) / (T::K / 2), vn = (uv + 1) % (T::K / 2);
-        const int tapn = (ry + 2 * un) * T::K + rx + 2 * vn;
-#pragma unroll
-        for (int g = 0; g < T::KG; ++g) b[(uv + 1) & 1][g] = ws.load((tapn * T::CT) * T::KG + g);
-      }
-#pragma unroll
-      for (int p = 0; p < T::P; ++p) {
-        const int pos = (p / T::H + u) * T::GA + p % T::H + v;
-#pragma unroll
-        for (int g = 0; g < T::KG; ++g) {
-          const f32x4 a = *(const f32x4*)(xa + p * T::CI + 16 * g);
-#pragma unroll
-          for (int m = 0; m < 4; ++m) acc[pos] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], b[uv & 1][g][m], acc[pos], 0, 0, 0);
-        }
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < T::GA * T::GA; ++i) {
-      const int oy = 2 * (i / T::GA) + ry, ox = 2 * (i % T::GA) + rx;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int img = n0 + 4 * q + r;
-        if (img < n_images) {
-          const float v = acc[i][r];
-          y[((size_t)img * T::NPIX + oy * T::HO + ox) * T::CO + 16 * c + j] = act ? fmaxf(v, 0.f) : v;
-        }
-      }
-    }
-  }
+  if (half == 0) few_fwd_half<T, 0>(xa, ws, bj, blockIdx.y, y, n0, n_images, c, act);
+  else few_fwd_half<T, 1>(xa, ws, bj, blockIdx.y, y, n0, n_images, c, act);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -789,7 +801,7 @@ int rlgan_deconv_fused_forward(const rlgan_deconv_t* d, const float* x, const fl
                        x, wff, bias, y, n_images, act_relu);
   } else if (kind == FUSED_FEW_FWD) {
     allow_lds(deconv_few_fwd_kernel<Few>, Few::FWD_LDS);
-    hipLaunchKernelGGL(deconv_few_fwd_kernel<Few>, dim3(cdiv(n_images, 16), 4), dim3(256), Few::FWD_LDS, (hipStream_t)stream,
+    hipLaunchKernelGGL(deconv_few_fwd_kernel<Few>, dim3(cdiv(n_images, 16), 4), dim3(512), Few::FWD_LDS, (hipStream_t)stream,
                        x, wff, bias, y, n_images, act_relu);
   } else {
     allow_lds(deconv_narrow_fwd_kernel<Last>, Last::FWD_LDS);
