@@ -554,8 +554,14 @@ __global__ __launch_bounds__(256) void deconv_narrow_fwd_kernel(const float* __r
 
 // dX[n][pixel][ci] = sum over taps of dZ[pixel(tap)] W[tap][ci] and slabs[chunk][tap][ci] = sum over the chunk's
 // images and pixels of dZ[pixel(tap)] X[pixel][ci].  grid = chunks; the 16-pixel tiles of an image go round the waves.
+// Waves of the narrow layer's backward kernel.  (Eight, with registers capped for four waves per SIMD: 158 -> 163 us per
+// 4096 images; the 23 row tiles of an image do not divide over eight waves and the kernel is not short of waves.)
+#ifndef RLGAN_NBW
+#define RLGAN_NBW 4
+#endif
+constexpr int NBW = RLGAN_NBW;
 template <class N, bool DX>
-__global__ __launch_bounds__(256) void deconv_narrow_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+__global__ __launch_bounds__(NBW * 64, NBW / 2) void deconv_narrow_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                                  const float* __restrict__ yact, const float* __restrict__ wfb,
                                                                  float* __restrict__ dx, float* __restrict__ slabs,
                                                                  int n_images, int per_chunk) {
@@ -566,7 +572,7 @@ __global__ __launch_bounds__(256) void deconv_narrow_bwd_kernel(const float* __r
   const int lane = threadIdx.x & 63, wave = wave_id(), q = lane >> 4, j = lane & 15;
   const int chunk = blockIdx.x;
   const int n0 = chunk * per_chunk, n1 = min(n_images, n0 + per_chunk);
-  for (int p = threadIdx.x; p < N::PP; p += 256) {
+  for (int p = threadIdx.x; p < N::PP; p += NBW * 64) {
     const int px = min(p, N::P - 1);
     pixtab[p] = (2 * (px / N::H)) * N::HO + 2 * (px % N::H);
   }
@@ -591,21 +597,21 @@ __global__ __launch_bounds__(256) void deconv_narrow_bwd_kernel(const float* __r
   }
   // An image's operands travel memory -> registers while the previous image is multiplied out of LDS, every piece of
   // them requested at once (a piece per loop turn was a memory round trip per turn, eighteen per image).
-  constexpr int DU = (N::NO + 255) / 256, XI = (N::PP / 4) * N::CI, XU = (XI + 255) / 256;
+  constexpr int NTH = NBW * 64, DU = (N::NO + NTH - 1) / NTH, XI = (N::PP / 4) * N::CI, XU = (XI + NTH - 1) / NTH;
   float dreg[DU], yreg[DU];
   f32x4 xreg[XU];
   auto fetch = [&](int n) {
     const float* dyn = dy + (size_t)n * N::NO;
 #pragma unroll
     for (int u = 0; u < DU; ++u) {
-      const int o = min((int)threadIdx.x + 256 * u, N::NO - 1);
+      const int o = min((int)threadIdx.x + NTH * u, N::NO - 1);
       dreg[u] = dyn[o];
       yreg[u] = yact ? yact[(size_t)n * N::NO + o] : 1.f;
     }
     const float* xn = x + (size_t)n * N::P * N::CI;
 #pragma unroll
     for (int u = 0; u < XU; ++u) {
-      const int i = min((int)threadIdx.x + 256 * u, XI - 1), pg = i / N::CI, ci = i % N::CI;
+      const int i = min((int)threadIdx.x + NTH * u, XI - 1), pg = i / N::CI, ci = i % N::CI;
 #pragma unroll
       for (int e = 0; e < 4; ++e) xreg[u][e] = xn[min(4 * pg + e, N::P - 1) * N::CI + ci];
     }
@@ -615,12 +621,12 @@ __global__ __launch_bounds__(256) void deconv_narrow_bwd_kernel(const float* __r
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < DU; ++u) {
-      const int o = threadIdx.x + 256 * u;
+      const int o = threadIdx.x + NTH * u;
       if (o < N::NO) Dimg[o] = yact ? dreg[u] * relu_d(yreg[u]) : dreg[u];
     }
 #pragma unroll
     for (int u = 0; u < XU; ++u) {
-      const int i = threadIdx.x + 256 * u;
+      const int i = threadIdx.x + NTH * u;
       if (i < XI) {
         const int pg = i / N::CI;
         f32x4 v;
@@ -631,7 +637,7 @@ __global__ __launch_bounds__(256) void deconv_narrow_bwd_kernel(const float* __r
     }
     __syncthreads();
     if (n + 1 < n1) fetch(n + 1);
-    for (int t = wave; t < N::MT; t += 4) {
+    for (int t = wave; t < N::MT; t += NBW) {
       if (DX) {
         const int pb = pixtab[16 * t + j];
         f32x4 accx[N::NTC];
@@ -668,9 +674,10 @@ __global__ __launch_bounds__(256) void deconv_narrow_bwd_kernel(const float* __r
       }
     }
   }
-  // the four waves' partial kernels, added in wave order
+  // the waves' partial kernels, added in wave order
   __syncthreads();
-  float* red = Xt;                                         // [4 waves][NTILES][64 lanes][4]
+  float* red = lds;                                        // [NBW waves][NTILES][64 lanes][4], over the image and the input
+  static_assert(NBW * N::NTILES * 256 <= N::NO + N::XT, "the cross-wave sum reuses the operands' space");
 #pragma unroll
   for (int tt = 0; tt < N::NTN; ++tt) {
 #pragma unroll
@@ -678,13 +685,16 @@ __global__ __launch_bounds__(256) void deconv_narrow_bwd_kernel(const float* __r
   }
   __syncthreads();
   float* out = slabs + (size_t)chunk * N::KW;
-  for (int i = threadIdx.x; i < N::NTILES * 256; i += 256) {
+  for (int i = threadIdx.x; i < N::NTILES * 256; i += NTH) {
     const int tile = i >> 8, el = i & 255, ln = el >> 2, r = el & 3;
     const int tt = tile / N::NTC, nt = tile % N::NTC;
     const int tap = 16 * tt + 4 * (ln >> 4) + r, ci = 16 * nt + (ln & 15);
     if (tap < N::KK) {
       const float* p = red + tile * 256 + el;
-      out[tap * N::CI + ci] = ((p[0] + p[N::NTILES * 256]) + p[2 * N::NTILES * 256]) + p[3 * N::NTILES * 256];
+      float tot = p[0];
+#pragma unroll
+      for (int w = 1; w < NBW; ++w) tot += p[w * N::NTILES * 256];
+      out[tap * N::CI + ci] = tot;
     }
   }
 }
@@ -840,10 +850,10 @@ int rlgan_deconv_fused_backward(const rlgan_deconv_t* d, const float* x, const f
   float* slabs = workspace;
   float* colsum_scratch = slabs + (size_t)nch * Last::KW;
   if (dx) {
-    hipLaunchKernelGGL((deconv_narrow_bwd_kernel<Last, true>), dim3(nch), dim3(256), Last::BWD_LDS, st, x, dy, y_relu, wfb, dx, slabs,
+    hipLaunchKernelGGL((deconv_narrow_bwd_kernel<Last, true>), dim3(nch), dim3(NBW * 64), Last::BWD_LDS, st, x, dy, y_relu, wfb, dx, slabs,
                        n_images, per);
   } else {
-    hipLaunchKernelGGL((deconv_narrow_bwd_kernel<Last, false>), dim3(nch), dim3(256), Last::BWD_LDS, st, x, dy, y_relu, wfb, dx, slabs,
+    hipLaunchKernelGGL((deconv_narrow_bwd_kernel<Last, false>), dim3(nch), dim3(NBW * 64), Last::BWD_LDS, st, x, dy, y_relu, wfb, dx, slabs,
                        n_images, per);
   }
   if (const int rc = launched()) return rc;
