@@ -26,7 +26,7 @@ for li, L in enumerate(enc.layers):
     flops = 2.0 * y.numel() * (L.k * L.k * L.c_in + 1)
     print(f"layer {li + 1}: in {tuple(x.shape[1:])} out {tuple(y.shape[1:])}  wgrad {t:7.1f} us ({flops / t * 1e-6:6.1f} TFLOP/s)  "
           f"sum {gr.sum().item():.6f} abs {gr.abs().sum().item():.6f}")
-    if li > 0:
+    if True:                     # the first layer's input gradient too: the generator's image is its input
         dx = L.backward(x, y, dy, need_dx=True, need_dw=False)
         td = min(timeit_graph(lambda: L.backward(x, y, dy, need_dx=True, need_dw=False), reps=10) for _ in range(3))
         print(f"         dx {td:7.1f} us ({flops / td * 1e-6:6.1f} TFLOP/s)  sum {dx.double().sum().item():.6f} abs {dx.double().abs().sum().item():.6f}")
