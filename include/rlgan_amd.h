@@ -460,6 +460,19 @@ int rlgan_deconv_place(const rlgan_deconv_t* deconv, const float* cols, const fl
 /* dcols[(n, iy, ix)][(ky, kx, co)] = dy[n, iy*stride + ky, ix*stride + kx, co] (* ReLU'(y_relu) when y_relu != NULL) */
 int rlgan_deconv_gather(const rlgan_deconv_t* deconv, const float* dy, const float* y_relu, float* dcols, int n_images,
                         void* stream);
+/* The two products of the backward pass that read dcols, reading dz = dy * ReLU'(y) (rlgan_relu_backward; dy itself for
+ * a layer without activation) in place of it: element [(n, iy, ix)][(ky, kx, co)] of dcols IS dz[n, iy*stride + ky,
+ * ix*stride + kx, co], so rlgan_deconv_gather and its matrix (151 MB for 3x3x128 -> 8x8x64 at 4096 images) are not
+ * needed (Conv_model.py:463, the backward pass TensorFlow derives for it).  Same tiles, products and order as
+ * rlgan_dense_backward_input_split / rlgan_dense_backward_kernel on dcols: the same bits.  For whole tiles only:
+ * rlgan_deconv_view_ok says whether n_images * h * w, c_in, k*k*c_out and c_out are all multiples of 64 (1) or the
+ * cols form has to be used (0); the two products return RLGAN_E_DIMS in that case.
+ * dx[n*h*w][c_in] = dcols * Wmat[0:c_in]^T;  gw[c_in][kk] = x2d^T * dcols;  slabs / n_slabs as in the dense products. */
+int rlgan_deconv_view_ok(const rlgan_deconv_t* deconv, int n_images);
+int rlgan_deconv_backward_input_view(const rlgan_deconv_t* deconv, const float* dz, const float* wmat, float* dx, int n_images,
+                                     float* slabs, int n_slabs, void* stream);
+int rlgan_deconv_backward_kernel_view(const rlgan_deconv_t* deconv, const float* x, const float* dz, float* gw, int n_images,
+                                      float* slabs, int n_slabs, void* stream);
 /* out[c] = sum over rows of dy[r][c] (* ReLU'(y_relu[r][c]) when y_relu != NULL), n_cols <= 256, in a fixed order
  * (bias gradient of a layer); partial: scratch of 512 * n_cols floats. */
 int rlgan_column_sums(const float* dy, const float* y_relu, int64_t rows, int32_t n_cols, float* partial, float* out,

@@ -197,6 +197,9 @@ PROTOTYPES = {
     "rlgan_deconv_build_map": [C.POINTER(Deconv), _vp],
     "rlgan_deconv_place": [C.POINTER(Deconv), _vp, _vp, _vp, _i, _i, _vp],
     "rlgan_deconv_gather": [C.POINTER(Deconv), _vp, _vp, _vp, _i, _vp],
+    "rlgan_deconv_view_ok": [C.POINTER(Deconv), _i],
+    "rlgan_deconv_backward_input_view": [C.POINTER(Deconv), _vp, _vp, _vp, _i, _vp, _i, _vp],
+    "rlgan_deconv_backward_kernel_view": [C.POINTER(Deconv), _vp, _vp, _vp, _i, _vp, _i, _vp],
     "rlgan_deconv_fused_geometry": [C.POINTER(Deconv), C.POINTER(DeconvFusedGeom)],
     "rlgan_deconv_fused_build_maps": [C.POINTER(Deconv), _vp, _vp],
     "rlgan_deconv_fused_forward": [C.POINTER(Deconv), _vp, _vp, _vp, _vp, _i, _i, _vp],

@@ -9,6 +9,7 @@
 // Wb is the canonical parameter block, the [K, N] kernel followed by the bias row.  gfx950 only.
 #include "rlgan_device.h"
 #include "rlgan_host.h"
+#include "fastdiv.h"
 #include <algorithm>
 #include <cstdint>
 #include <type_traits>
@@ -25,6 +26,26 @@ constexpr int F4R = BK / 4, TL = BK / 16;   // float4 per tile row; float4 per t
 constexpr int LDT = BK + 4;                 // LDS row: 36 floats, the 16 rows of an MFMA lane group fall on disjoint banks
 constexpr int TILE_FLOATS = 64 * LDT;
 
+// An operand that is the cols matrix of a transposed convolution without the matrix in memory:
+//   cols[(n, iy, ix)][(ky, kx, c)] = z[((n * Ho + iy * s + ky) * Wo + ix * s + kx) * Co + c]
+// -- an element's address is a row part plus a column part.  Used for whole tiles only (the host checks the extents),
+// with Co a multiple of the tile's extent along (ky, kx, c), so that the tap of a tile is uniform.
+struct ColsView {
+  int P, w;                   // input pixels per image, per input row
+  FastDiv dP, dw, dk;
+  int img, rowstep, colstep;  // floats per output image, per s output rows, per s output pixels
+  int Co, k, Wo;
+  __device__ __forceinline__ int row_off(int r) const {
+    const int n = fdiv(r, dP), p = r - n * P, iy = fdiv(p, dw), ix = p - iy * w;
+    return n * img + iy * rowstep + ix * colstep;
+  }
+  // e0: first column of the tile (uniform), de: this lane's distance from it (< Co - e0 % Co)
+  __device__ __forceinline__ int col_off(int e0, int de) const {
+    const int tap = e0 / Co, ky = fdiv(tap, dk), kx = tap - ky * k;
+    return (ky * Wo + kx) * Co + (e0 - tap * Co) + de;
+  }
+};
+
 struct GemmArgs {
   const float* a; const float* b; float* c;
   int lda, ldb, ldc;
@@ -36,6 +57,7 @@ struct GemmArgs {
   int quads;            // every aligned group of four along the contiguous dimension of A and of B is inside or outside as a whole
   int k_split;          // reduction indices per blockIdx.y (a multiple of BK); with more than one split the
   size_t slab;          // raw partial products go to c + blockIdx.y * slab and split_sum_kernel finishes
+  ColsView view;        // of operand A (gemm_kernel<.., .., 1>) or B (<.., .., 2>)
 };
 
 // One operand tile, 64 (x: rows of A / columns of B) by BK (k), as two float4 per thread.
@@ -115,6 +137,17 @@ __device__ __forceinline__ void tile_load_inside(f32x4 (&r)[TL], const float* __
                  : *(const f32x4*)(p + (size_t)(k0 + (u >> 4)) * ld + x0 + (u & 15) * 4);
   }
 }
+// The same through a ColsView: KCONT = rows of the view are the x, its columns the k (operand A of the input gradient);
+// otherwise its rows are the k and its columns the x (operand B of the kernel gradient).
+template <bool KCONT>
+__device__ __forceinline__ void tile_load_view(f32x4 (&r)[TL], const float* __restrict__ p, const ColsView& v, int x0, int k0) {
+#pragma unroll
+  for (int h = 0; h < TL; ++h) {
+    const int u = threadIdx.x + 256 * h;
+    r[h] = KCONT ? *(const f32x4*)(p + v.row_off(x0 + u / F4R) + v.col_off(k0, (u % F4R) * 4))
+                 : *(const f32x4*)(p + v.row_off(k0 + (u >> 4)) + v.col_off(x0, (u & 15) * 4));
+  }
+}
 // Position of reduction index k in row x of an LDS tile: the row's eight 4-float groups are permuted by the row's
 // 16-row block (k ^ 0, 4, 8 or 12).  A 16-byte operand read stays one aligned group; the transposing store below,
 // whose sixteen x-quads per k would otherwise fall on four banks four deep, spreads over all 64 banks.
@@ -140,7 +173,7 @@ __device__ __forceinline__ void tile_store(float* t, const f32x4 (&r)[TL]) {
 // flight through further register sets: 1 to 2 % slower at batch 4096 and no faster at batch 32, where a product with
 // few output tiles is a chain of memory round trips per workgroup -- what helps there is cutting the reduction into
 // slabs, which every product can now ask for.)
-template <bool A_KCONT, bool B_KCONT>
+template <bool A_KCONT, bool B_KCONT, int VIEW = 0>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];           // 4 * TILE_FLOATS: A and B tiles, two stages
   // Workgroups go to the eight XCDs in turn, each with an L2 of its own: workgroup f of the launch takes the f/8-th
@@ -177,12 +210,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
     if (g.ones_k >= 0) kin = min(kin, g.ones_k);
     nin = max(0, min(nkt, (kin - kb) / BK));
   }
+  if constexpr (VIEW != 0) nin = nkt;                               // a view is launched on whole tiles only
   // mode 0: inside, 1: border by groups of four, 2: border by elements.  The mode is chosen outside the loops: a
   // branch between the loads and the products would make the wave wait for the loads where its arms join.
   auto load = [&](int kt, auto mode) {
     if constexpr (mode.value == 0) {
-      tile_load_inside<A_KCONT>(ra, g.a, g.lda, m0, kb + kt * BK);
-      tile_load_inside<B_KCONT>(rb, g.b, g.ldb, n0, kb + kt * BK);
+      if constexpr (VIEW == 1) tile_load_view<A_KCONT>(ra, g.a, g.view, m0, kb + kt * BK);
+      else tile_load_inside<A_KCONT>(ra, g.a, g.lda, m0, kb + kt * BK);
+      if constexpr (VIEW == 2) tile_load_view<B_KCONT>(rb, g.b, g.view, n0, kb + kt * BK);
+      else tile_load_inside<B_KCONT>(rb, g.b, g.ldb, n0, kb + kt * BK);
     } else if constexpr (mode.value == 1) {
       tile_load_quads<A_KCONT>(ra, g.a, g.lda, m0, kb + kt * BK, ax, ak, g.ones_x, g.ones_k);
       tile_load_quads<B_KCONT>(rb, g.b, g.ldb, n0, kb + kt * BK, g.b_x, g.b_k, -1, -1);
@@ -327,30 +363,32 @@ inline int launched() { return (int)hipGetLastError(); }
 // The reduction is cut into n_slabs ranges when the C tiles alone would leave the chip idle or a
 // workgroup alone on its compute unit with nothing to cover its loads: partial products to `slabs`
 // ([n_slabs][M][N]), then one pass adds them in order and applies the activation.
-template <bool A_KCONT, bool B_KCONT>
+template <bool A_KCONT, bool B_KCONT, int VIEW = 0>
 int launch_gemm(GemmArgs g, float* slabs, int n_slabs, void* stream) {
   if (!g.a || !g.b || !g.c || g.M <= 0 || g.N <= 0 || g.K <= 0 || n_slabs < 0 || n_slabs > 256 || (n_slabs > 1 && !slabs))
     return RLGAN_E_ARG;
   // float4 loads: 16-byte aligned bases and leading dimensions that are multiples of four
   if (!aligned16(g.a) || !aligned16(g.b) || (g.lda & 3) || (g.ldb & 3)) return RLGAN_E_ALIGN;
+  // a view is read by whole tiles only
+  if (VIEW != 0 && ((g.M % BM) || (g.N % BN) || (g.K % BK) || g.ones_x >= 0 || g.ones_k >= 0)) return RLGAN_E_DIMS;
   const long long blocks = (long long)cdiv(g.M, BM) * cdiv(g.N, BN);
   if (blocks > 0x7fffffffll) return RLGAN_E_ARG;
   g.k_split = g.K; g.slab = 0;
   g.quads = (A_KCONT ? g.a_k : g.a_x) % 4 == 0 && (B_KCONT ? g.b_k : g.b_x) % 4 == 0;
   constexpr size_t GEMM_LDS = (size_t)4 * TILE_FLOATS * sizeof(float);
-  if (GEMM_LDS > 64 * 1024) (void)hipFuncSetAttribute((const void*)gemm_kernel<A_KCONT, B_KCONT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS);
+  if (GEMM_LDS > 64 * 1024) (void)hipFuncSetAttribute((const void*)gemm_kernel<A_KCONT, B_KCONT, VIEW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS);
   int nz = 1;
   if (n_slabs > 1) {
     g.k_split = BK * cdiv(cdiv(g.K, n_slabs), BK);
     nz = cdiv(g.K, g.k_split);
   }
   if (nz == 1) {
-    hipLaunchKernelGGL((gemm_kernel<A_KCONT, B_KCONT>), dim3((unsigned)blocks), dim3(256), GEMM_LDS, (hipStream_t)stream, g);
+    hipLaunchKernelGGL((gemm_kernel<A_KCONT, B_KCONT, VIEW>), dim3((unsigned)blocks), dim3(256), GEMM_LDS, (hipStream_t)stream, g);
     return launched();
   }
   float* out = g.c; const int ldc = g.ldc, act = g.act;
   g.c = slabs; g.ldc = g.N; g.act = 0; g.slab = (size_t)g.M * g.N;
-  hipLaunchKernelGGL((gemm_kernel<A_KCONT, B_KCONT>), dim3((unsigned)blocks, nz), dim3(256), GEMM_LDS, (hipStream_t)stream, g);
+  hipLaunchKernelGGL((gemm_kernel<A_KCONT, B_KCONT, VIEW>), dim3((unsigned)blocks, nz), dim3(256), GEMM_LDS, (hipStream_t)stream, g);
   hipLaunchKernelGGL(split_sum_kernel, dim3((unsigned)cdiv((long long)g.M * g.N, 256)), dim3(256), 0, (hipStream_t)stream,
                      slabs, nz, g.slab, g.M, g.N, out, ldc, act);
   return launched();
@@ -414,6 +452,45 @@ int rlgan_dense_backward_kernel(const float* x, int ldx, const float* dz, int ld
   // the same product without the ones row: a k that is a multiple of the 64-row tile gets no extra row of tiles for it
   GemmArgs g{x, dz, gw, ldx, lddz, n, k, n, m, /*a_x*/ k, /*a_k*/ m, /*b_x*/ n, /*b_k*/ m, /*ones_x*/ -1, /*ones_k*/ -1, 0, 0, 0};
   return launch_gemm<false, false>(g, slabs, n_slabs, stream);
+}
+
+// The two products of a transposed convolution's backward pass that read the cols matrix, reading dZ = dY * ReLU'(Y)
+// through a ColsView instead (rlgan_deconv_gather wrote 151 MB of cols for the 3x3x128 -> 8x8x64 layer at 4096 images and
+// both products read them back).  Same tiles, same products in the same order as the cols form: the same bits.
+static bool cols_view(const rlgan_deconv_t* d, int n_images, ColsView* v) {
+  if (!d || d->h <= 0 || d->w <= 0 || d->k <= 0 || d->stride <= 0 || d->c_in <= 0 || d->c_out <= 0 || n_images <= 0) return false;
+  const long long rows = (long long)n_images * d->h * d->w, kk = (long long)d->k * d->k * d->c_out;
+  const int Ho = (d->h - 1) * d->stride + d->k, Wo = (d->w - 1) * d->stride + d->k;
+  if ((long long)n_images * Ho * Wo * d->c_out > 0x7fffffffll || rows > 0x7fffffffll) return false;
+  if ((rows % BM) || (d->c_in % BM) || (kk % BN) || (d->c_out % BN)) return false;   // whole tiles, one tap per tile
+  v->P = d->h * d->w; v->w = d->w;
+  v->dP = make_div(v->P); v->dw = make_div(d->w); v->dk = make_div(d->k);
+  v->img = Ho * Wo * d->c_out; v->rowstep = d->stride * Wo * d->c_out; v->colstep = d->stride * d->c_out;
+  v->Co = d->c_out; v->k = d->k; v->Wo = Wo;
+  return true;
+}
+
+int rlgan_deconv_view_ok(const rlgan_deconv_t* d, int n_images) {
+  ColsView v;
+  return cols_view(d, n_images, &v) ? 1 : 0;
+}
+
+int rlgan_deconv_backward_input_view(const rlgan_deconv_t* d, const float* dz, const float* wmat, float* dx, int n_images,
+                                     float* slabs, int n_slabs, void* stream) {
+  ColsView v;
+  if (!cols_view(d, n_images, &v)) return RLGAN_E_DIMS;
+  const int rows = n_images * d->h * d->w, kk = d->k * d->k * d->c_out;
+  GemmArgs g{dz, wmat, dx, kk, kk, d->c_in, rows, d->c_in, kk, rows, kk, /*b_x*/ d->c_in, /*b_k*/ kk, -1, -1, 0, 0, 0, 0, v};
+  return launch_gemm<true, true, 1>(g, slabs, n_slabs, stream);
+}
+
+int rlgan_deconv_backward_kernel_view(const rlgan_deconv_t* d, const float* x, const float* dz, float* gw, int n_images,
+                                      float* slabs, int n_slabs, void* stream) {
+  ColsView v;
+  if (!cols_view(d, n_images, &v)) return RLGAN_E_DIMS;
+  const int rows = n_images * d->h * d->w, kk = d->k * d->k * d->c_out;
+  GemmArgs g{x, dz, gw, d->c_in, kk, kk, d->c_in, kk, rows, /*a_x*/ d->c_in, /*a_k*/ rows, /*b_x*/ kk, /*b_k*/ rows, -1, -1, 0, 0, 0, 0, v};
+  return launch_gemm<false, false, 2>(g, slabs, n_slabs, stream);
 }
 
 }  // extern "C"

@@ -22,6 +22,8 @@ class DeconvLayer:
     """One conv2d_transpose (+ ReLU) layer.  Parameters in canonical order: TensorFlow's kernel
     [k, k, c_out, c_in], then the bias."""
 
+    cols_view = True      # backward products read dz through a view of the cols matrix where the extents allow it (tests turn it off to compare)
+
     def __init__(self, h: int, w: int, c_in: int, c_out: int, k: int, stride: int, rng: Optional[np.random.RandomState] = None,
                  bias_init: float = 0.0, kernel: Optional[np.ndarray] = None, bias: Optional[np.ndarray] = None, fused: bool = True):
         """fused=False keeps the cols form for a shape that has a fused kernel (the two forms are compared in the tests)."""
@@ -131,12 +133,27 @@ class DeconvLayer:
                                                   None if dx is None else dx.data_ptr(), self._ws.data_ptr(), self.grad.data_ptr(), n,
                                                   _stream()), "rlgan_deconv_fused_backward")
             return dx
-        dcols = self._cols_buffer(rows)
-        check(lib.rlgan_deconv_gather(self.spec, dy.data_ptr(), yr, dcols.data_ptr(), n, _stream()), "rlgan_deconv_gather")
+        # dcols[(n, iy, ix)][(ky, kx, co)] is an element of dz = dy * ReLU'(y): where the layer's extents are whole tiles the
+        # two products below read dz in place and the matrix is never written
+        view = self.cols_view and lib.rlgan_deconv_view_ok(self.spec, n) == 1
+        if view:
+            if act:
+                dz = torch.empty_like(dy)
+                check(lib.rlgan_relu_backward(dy.data_ptr(), y.data_ptr(), dz.data_ptr(), dy.numel(), _stream()), "rlgan_relu_backward")
+            else:
+                dz = dy
+        else:
+            dcols = self._cols_buffer(rows)
+            check(lib.rlgan_deconv_gather(self.spec, dy.data_ptr(), yr, dcols.data_ptr(), n, _stream()), "rlgan_deconv_gather")
         sc, ns = self._slabs(self.c_in, self.kk, rows)            # the kernel gradient alone: the bias gradient is a column sum of dy (below)
-        check(lib.rlgan_dense_backward_kernel(x.data_ptr(), self.c_in, dcols.data_ptr(), self.kk, self._gmat.data_ptr(), rows, self.c_in,
-                                              self.kk, None if sc is None else sc.data_ptr(), ns, _stream()),
-              "rlgan_dense_backward_kernel")
+        if view:
+            check(lib.rlgan_deconv_backward_kernel_view(self.spec, x.data_ptr(), dz.data_ptr(), self._gmat.data_ptr(), n,
+                                                        None if sc is None else sc.data_ptr(), ns, _stream()),
+                  "rlgan_deconv_backward_kernel_view")
+        else:
+            check(lib.rlgan_dense_backward_kernel(x.data_ptr(), self.c_in, dcols.data_ptr(), self.kk, self._gmat.data_ptr(), rows, self.c_in,
+                                                  self.kk, None if sc is None else sc.data_ptr(), ns, _stream()),
+                  "rlgan_dense_backward_kernel")
         nk = self.kk * self.c_in
         check(lib.rlgan_gather_map(self._gmat.data_ptr(), self.map_w.data_ptr(), nk, self.grad.data_ptr(), _stream()), "rlgan_gather_map")
         check(lib.rlgan_column_sums(dy.data_ptr(), yr, n * self.h_out * self.w_out, self.c_out, self._colsum.data_ptr(),
@@ -145,6 +162,11 @@ class DeconvLayer:
             return None
         dx = torch.empty_like(x)
         sc, ns = self._slabs(rows, self.c_in, self.kk)
+        if view:
+            check(lib.rlgan_deconv_backward_input_view(self.spec, dz.data_ptr(), self.wmat.data_ptr(), dx.data_ptr(), n,
+                                                       None if sc is None else sc.data_ptr(), ns, _stream()),
+                  "rlgan_deconv_backward_input_view")
+            return dx
         check(lib.rlgan_dense_backward_input_split(dcols.data_ptr(), self.kk, self.wmat.data_ptr(), dx.data_ptr(), self.c_in, rows, self.c_in,
                                                    self.kk, None if sc is None else sc.data_ptr(), ns, _stream()),
               "rlgan_dense_backward_input_split")

@@ -57,6 +57,38 @@ def test_layer_forward_and_backward(h, ci, co, k, s, act, n):
         close(dxt.cpu().numpy(), dx3.cpu().numpy().astype(np.float64), what="dx, fused against cols")
 
 
+@pytest.mark.parametrize("act,n", [(True, 64), (False, 128)])
+def test_backward_products_through_the_cols_view(act, n):
+    """3x3x128 -> 8x8x64 (dec_deconv2, Conv_model.py:463) with a batch whose extents are whole tiles: the backward products
+    read dz in place of the gathered cols matrix and leave the bits of the cols form; against float64 as well."""
+    import rl_gan_amd as R
+    from rl_gan_amd import _lib
+    from gpu_util import close
+    from oracle import deconv as od
+    rng = np.random.RandomState(n)
+    f32 = lambda a: a.astype(np.float32).astype(np.float64)
+    x = f32(rng.standard_normal((n, 3, 3, 128)))
+    w = f32(rng.standard_normal((4, 4, 64, 128)) * 0.1)
+    b = f32(rng.standard_normal(64) * 0.1)
+    y, cache = od.deconv_forward(x, w, b, 2, act)
+    dy = f32(rng.standard_normal(y.shape))
+    dx, dw, db = od.deconv_backward(dy, w, cache, 2, act)
+    L = R.DeconvLayer(3, 3, 128, 64, 4, 2, kernel=w, bias=b)
+    assert _lib.lib.rlgan_deconv_view_ok(L.spec, n) == 1 and _lib.lib.rlgan_deconv_view_ok(L.spec, n + 1) == 0
+    xt, dyt = torch.from_numpy(x.astype(np.float32)).cuda(), torch.from_numpy(dy.astype(np.float32)).cuda()
+    yt = L.forward(xt, act=act)
+    dx_view = L.backward(xt, yt, dyt, act=act)
+    g_view = L.grad.clone()
+    close(dx_view.cpu().numpy(), dx, what="dx through the view")
+    close(g_view.cpu().numpy()[:dw.size].reshape(dw.shape), dw, what="dW through the view")
+    close(g_view.cpu().numpy()[dw.size:], db, what="db")
+    L.cols_view = False
+    dx_cols = L.backward(xt, yt, dyt, act=act)
+    assert torch.equal(dx_cols, dx_view) and torch.equal(L.grad, g_view)
+    # a batch that is not whole tiles is refused by the products themselves
+    assert _lib.lib.rlgan_deconv_backward_input_view(L.spec, dyt.data_ptr(), L.wmat.data_ptr(), dx_view.data_ptr(), n - 1, None, 1, None) == -2
+
+
 def test_decoder_end_to_end():
     import rl_gan_amd as R
     from gpu_util import close
