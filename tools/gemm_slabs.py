@@ -28,7 +28,7 @@ prods = (("forward", m, n, k + 1, lambda ns: lib.rlgan_dense_forward(x.data_ptr(
 for name, mo, no, kr, f in prods:
     sug = lib.rlgan_dense_slabs(mo, no, kr)
     out = []
-    for ns in (1, 2, 3, 4, 6, 8, 12, 16, 24, 32):
+    for ns in (1, 2, 3, 4, 6, 8, 10, 11, 12, 13, 14, 16, 24, 32):
         if ns * mo * no > slabs.numel():
             continue
         t = min(timeit_graph(lambda: f(ns), reps=10) for _ in range(2))
