@@ -175,7 +175,6 @@ __device__ __forceinline__ void tile_store(float* t, const f32x4 (&r)[TL]) {
 // slabs, which every product can now ask for.)
 template <bool A_KCONT, bool B_KCONT, int VIEW = 0>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
-
   extern __shared__ __attribute__((aligned(16))) float lds[];           // 4 * TILE_FLOATS: A and B tiles, two stages
   // Workgroups go to the eight XCDs in turn, each with an L2 of its own: workgroup f of the launch takes the f/8-th
   // of the run of (tile, slab) pairs that belongs to XCD f%8, so that the column tiles that share the rows of A, and
