@@ -406,6 +406,13 @@ int rlgan_elu_backward(const float* dy, const float* y, float* dz, int64_t n, vo
  * as it is read, which saves the separate rlgan_elu_backward pass. */
 int rlgan_conv_backward_input(const rlgan_conv_t* conv, const float* dz, const float* y_elu, const float* w_canon, const float* wdx,
                               float* dx, int n_images, void* stream);
+/* The same with one more factor: when x_elu (this layer's input, i.e. the ELU output of the layer below, [n, h, w, c_in])
+ * is given, dx leaves multiplied by ELU'(x_elu) -- it is then the dZ of the layer below, whose own backward calls take
+ * it with y_elu = NULL and no longer read their layer output (for a 42x42x4 -> 20x20x32 first layer that output is
+ * 210 MB per 4096 frames, read by the weight gradient at the memory roof).  dx * ELU'(x) is the product those calls
+ * formed while reading: the same bits.  x_elu = NULL: rlgan_conv_backward_input. */
+int rlgan_conv_backward_input_dz(const rlgan_conv_t* conv, const float* dz, const float* y_elu, const float* w_canon, const float* wdx,
+                                 float* dx, const float* x_elu, int n_images, void* stream);
 /* grad (canonical order, kernel then bias) = sum over all output pixels.  `slabs`: device scratch of
  * n_slabs * slab_floats floats (one partial image per workgroup, added in a fixed order).  y_elu as above. */
 int rlgan_conv_backward_weights(const rlgan_conv_t* conv, const float* x, const float* dz, const float* y_elu, float* slabs,

@@ -192,6 +192,7 @@ PROTOTYPES = {
     "rlgan_conv_forward": [C.POINTER(Conv), _vp, _vp, _vp, _i, _i, _vp],
     "rlgan_elu_backward": [_vp, _vp, _vp, _i64, _vp],
     "rlgan_conv_backward_input": [C.POINTER(Conv), _vp, _vp, _vp, _vp, _vp, _i, _vp],
+    "rlgan_conv_backward_input_dz": [C.POINTER(Conv), _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "rlgan_conv_backward_weights": [C.POINTER(Conv), _vp, _vp, _vp, _vp, _i, _vp, _i, _vp],
     "rlgan_deconv_geometry": [C.POINTER(Deconv), C.POINTER(DeconvGeom)],
     "rlgan_deconv_build_map": [C.POINTER(Deconv), _vp],

@@ -112,19 +112,24 @@ class ConvLayer:
                                         self.wfrag.data_ptr(), y.data_ptr(), n, 1 if act else 0, _stream()), "rlgan_conv_forward_u8")
         return y
 
-    def backward_frames(self, frames: "FrameRef", y: torch.Tensor, dy: torch.Tensor, act: bool = True) -> None:
-        """Weight gradient of a first layer whose input is the uint8 ring (fills self.grad; frames get no gradient)."""
+    def backward_frames(self, frames: "FrameRef", y: torch.Tensor, dy: torch.Tensor, act: bool = True, dy_is_dz: bool = False) -> None:
+        """Weight gradient of a first layer whose input is the uint8 ring (fills self.grad; frames get no gradient).
+        dy_is_dz: dy is dZ already (the layer above multiplied its input gradient by ELU'(y))."""
         ring, idx = frames.ring, frames.idx
         slabs, ns = self._slab_buffer(frames.n)
         check(lib.rlgan_conv_backward_weights_u8(self.conv, ring.data_ptr(), ring.shape[0], None if idx is None else idx.data_ptr(),
-                                                 frames.scale, dy.data_ptr(), y.data_ptr() if act else None, slabs.data_ptr(),
+                                                 frames.scale, dy.data_ptr(), y.data_ptr() if act and not dy_is_dz else None, slabs.data_ptr(),
                                                  ns, self.grad.data_ptr(), frames.n, _stream()),
               "rlgan_conv_backward_weights_u8")
 
     def backward(self, x: torch.Tensor, y: torch.Tensor, dy: torch.Tensor, need_dx: bool = True, act: bool = True,
-                 need_dw: bool = True):
-        """Gradients of this layer: fills self.grad (kernel then bias) unless need_dw is False, returns dx or None."""
+                 need_dw: bool = True, dy_is_dz: bool = False, dx_elu: bool = False):
+        """Gradients of this layer: fills self.grad (kernel then bias) unless need_dw is False, returns dx or None.
+        dy_is_dz: dy is dZ = dY * ELU'(y) already.  dx_elu: x is the ELU output of the layer below and the returned gradient
+        is multiplied by ELU'(x), i.e. it is that layer's dZ (the pair saves both of that layer's backward kernels the read
+        of its output)."""
         n = x.shape[0]
+        act = act and not dy_is_dz
         use_mfma = self.wdx is not None and not self.gather_dx
         # ELU' is applied by the consumers as they read dy (no pass of its own) unless the gather kernel runs
         fuse = act and (use_mfma or (self.c_in == 4 and self.conv.stride <= 4) or not need_dx)   # four input channels at stride <= 4: a kernel of its own, ELU' included
@@ -139,9 +144,9 @@ class ConvLayer:
         if not need_dx:
             return None
         dx = torch.empty_like(x)
-        check(lib.rlgan_conv_backward_input(self.conv, dz.data_ptr(), yel, self.canon.data_ptr(),
-                                            self.wdx.data_ptr() if use_mfma else None, dx.data_ptr(), n, _stream()),
-              "rlgan_conv_backward_input")
+        check(lib.rlgan_conv_backward_input_dz(self.conv, dz.data_ptr(), yel, self.canon.data_ptr(),
+                                               self.wdx.data_ptr() if use_mfma else None, dx.data_ptr(), x.data_ptr() if dx_elu else None,
+                                               n, _stream()), "rlgan_conv_backward_input_dz")
         return dx
 
 
@@ -238,8 +243,9 @@ class SingleFrameConv(ConvLayer):
                 kern[ky, kx, 0] = blocks[ky // 2, kx // 2, 2 * (ky % 2) + kx % 2]
         return kern, g[nk:]
 
-    def backward(self, x, y, dy, need_dx: bool = True, act: bool = True, need_dw: bool = True):
-        dx = super().backward(x, y, dy, need_dx=need_dx, act=act, need_dw=need_dw)
+    def backward(self, x, y, dy, need_dx: bool = True, act: bool = True, need_dw: bool = True, dy_is_dz: bool = False,
+                 dx_elu: bool = False):
+        dx = super().backward(x, y, dy, need_dx=need_dx, act=act, need_dw=need_dw, dy_is_dz=dy_is_dz, dx_elu=dx_elu)
         if need_dw:
             self.grad.mul_(self.mask)                          # the seven entries outside the 3x3 window take no gradient
         return dx
@@ -413,12 +419,16 @@ class ConvEncoder:
         if self.head is not None:
             dfeat = self.head.backward(self._flat, self._out, dfeat.contiguous(), need_dw=need_dw)
         dy = dfeat.reshape(self._acts[-1].shape).contiguous()
-        for i in range(len(self.layers) - 1, -1, -1):
+        # every layer below the top gets its dZ from the layer above (that layer's input gradient times ELU' of its own input)
+        # and reads its output no more
+        top = len(self.layers) - 1
+        for i in range(top, -1, -1):
             if i == 0 and isinstance(self._acts[0], FrameRef):
                 if need_dw:
-                    self.layers[0].backward_frames(self._acts[0], self._acts[1], dy)
+                    self.layers[0].backward_frames(self._acts[0], self._acts[1], dy, dy_is_dz=i < top)
                 return None
-            dy = self.layers[i].backward(self._acts[i], self._acts[i + 1], dy, need_dx=need_dx or i > 0, need_dw=need_dw)
+            dy = self.layers[i].backward(self._acts[i], self._acts[i + 1], dy, need_dx=need_dx or i > 0, need_dw=need_dw,
+                                         dy_is_dz=i < top, dx_elu=i > 0)
         if need_dx and isinstance(self.layers[0], SingleFrameConv):
             dy = self.layers[0].ungroup(dy)
         return dy

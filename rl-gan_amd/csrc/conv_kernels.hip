@@ -911,7 +911,7 @@ __global__ __launch_bounds__(256) void conv_dx_c4_lds_kernel(const ConvG g, cons
 template <int NT>
 __global__ __launch_bounds__(256) void conv_dx_kernel(const ConvG g, const DxOff offs, const float* __restrict__ dz,
                                                       const float* __restrict__ yelu, const float* __restrict__ wdx,
-                                                      float* __restrict__ dx, int n_images) {
+                                                      float* __restrict__ dx, int n_images, const float* __restrict__ x_elu) {
   extern __shared__ int taps[];                 // [2][max_ng * 4]
   const DxClass c = dx_class(g, blockIdx.y);
   int *tapd = taps, *tapuv = taps + offs.max_ng * 4;
@@ -958,11 +958,18 @@ __global__ __launch_bounds__(256) void conv_dx_kernel(const ConvG g, const DxOff
   }
   // result fragment: rows = input channels 16t + 4*(lane>>4) + i, column = pixel lane&15
   if (pix0 + (lane & 15) >= Ml) return;
-  float* o = dx + (((size_t)b * g.H + (g.s * a + c.py)) * g.W + (g.s * bb + c.px)) * g.Cin;
+  const size_t oo = (((size_t)b * g.H + (g.s * a + c.py)) * g.W + (g.s * bb + c.px)) * g.Cin;
+  float* o = dx + oo;
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int n0 = 16 * t + (lane >> 4) * 4;
-    if (n0 < g.Cin) *(f32x4*)(o + n0) = acc[t];           // Cin % 4 == 0: four channels are in range together
+    if (n0 >= g.Cin) continue;                            // Cin % 4 == 0: four channels are in range together
+    f32x4 v = acc[t];
+    if (x_elu) {                                          // the result leaves as the dZ of the layer below
+      const f32x4 xe = *(const f32x4*)(x_elu + oo + n0);
+      v = f32x4{v[0] * elu_d(xe[0]), v[1] * elu_d(xe[1]), v[2] * elu_d(xe[2]), v[3] * elu_d(xe[3])};
+    }
+    *(f32x4*)(o + n0) = v;
   }
 }
 
@@ -978,7 +985,8 @@ constexpr int DXI_MAXF = 16;               // kernel fragments (k-groups x input
 template <int NT, int NGC>
 __device__ __forceinline__ void dx_img_class(const ConvG& g, const DxClass& c, FastDiv dnb, const float* __restrict__ Z, int ZS,
                                              const int* __restrict__ tapd, const int* __restrict__ tapuv,
-                                             const float* __restrict__ wl, float* __restrict__ dx0, int imgs, int zero_at) {
+                                             const float* __restrict__ wl, float* __restrict__ dx0, int imgs, int zero_at,
+                                             const float* __restrict__ xe0) {
   constexpr int MAXG = NGC > 0 ? NGC : DXI_MAXF / NT;
   const int lane = threadIdx.x & 63, wave = wave_id(), q0 = lane >> 4;
   const int ng = NGC > 0 ? NGC : c.NG;
@@ -1003,6 +1011,16 @@ __device__ __forceinline__ void dx_img_class(const ConvG& g, const DxClass& c, F
     const int a = fdiv(p, dnb), bb = p - a * c.nb;
     const int pz = (img * g.Ho * g.Wo + a * g.Wo + bb) * ZS;
     float* dxn = dx0 + (size_t)img * g.H * g.W * g.Cin;
+    // The layer input at this lane's result (xe0: the ELU output of the layer below), requested before the gathers; the
+    // result leaves as that layer's dZ.  (Requested a whole tile ahead instead: no change.  Probe builds: the reads cost
+    // the kernel 38 us per 4096 maps of 20x20x32, the multiplications nothing -- the 210 MB move here from the layer
+    // below's two backward kernels, which are bound by memory, and cost less here than there.)
+    const size_t oo = (size_t)img * g.H * g.W * g.Cin + ((size_t)(g.s * a + c.py) * g.W + (g.s * bb + c.px)) * g.Cin;
+    f32x4 xe[NT];
+    if (xe0) {
+#pragma unroll
+      for (int i = 0; i < NT; ++i) xe[i] = *(const f32x4*)(xe0 + oo + min(16 * i + q0 * 4, g.Cin - 4));
+    }
     f32x4 ad[MAXG];
 #pragma unroll
     for (int gi = 0; gi < MAXG; ++gi) {
@@ -1030,7 +1048,9 @@ __device__ __forceinline__ void dx_img_class(const ConvG& g, const DxClass& c, F
 #pragma unroll
       for (int i = 0; i < NT; ++i) {
         const int n0 = 16 * i + q0 * 4;
-        if (n0 < g.Cin) *(f32x4*)(o + n0) = acc[i];
+        f32x4 v = acc[i];
+        if (xe0) v = f32x4{v[0] * elu_d(xe[i][0]), v[1] * elu_d(xe[i][1]), v[2] * elu_d(xe[i][2]), v[3] * elu_d(xe[i][3])};
+        if (n0 < g.Cin) *(f32x4*)(o + n0) = v;
       }
     }
     t += 4;
@@ -1041,7 +1061,8 @@ __device__ __forceinline__ void dx_img_class(const ConvG& g, const DxClass& c, F
 template <int NT>
 __global__ __launch_bounds__(256) void conv_dx_img_kernel(const ConvG g, const DxOff offs, const float* __restrict__ dz,
                                                           const float* __restrict__ yelu, const float* __restrict__ wdx,
-                                                          float* __restrict__ dx, int n_images, int imgs_per_wg) {
+                                                          float* __restrict__ dx, int n_images, int imgs_per_wg,
+                                                          const float* __restrict__ x_elu) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int ZS = g.Cout + 4, C4 = g.Cout >> 2;
   const int n = blockIdx.x * imgs_per_wg, imgs = min(imgs_per_wg, n_images - n);
@@ -1084,6 +1105,7 @@ __global__ __launch_bounds__(256) void conv_dx_img_kernel(const ConvG g, const D
   }
   __syncthreads();
   float* dxn = dx + (size_t)n * g.H * g.W * g.Cin;
+  const float* xen = x_elu ? x_elu + (size_t)n * g.H * g.W * g.Cin : nullptr;
   const int imgs_here = imgs;
   for (int cls = 0; cls < ncls; ++cls) {                   // no barrier below: every wave walks the classes at its own pace
     const DxClass c = dx_class(g, cls);
@@ -1091,11 +1113,11 @@ __global__ __launch_bounds__(256) void conv_dx_img_kernel(const ConvG g, const D
     const float* wl = wdx + offs.off[cls] + (threadIdx.x & 63) * 4;
     switch (c.NG) {
       case 0: break;
-      case 1: dx_img_class<NT, 1>(g, c, offs.dnb[cls], Z, ZS, tapd, tapuv, wl, dxn, imgs_here, zero_at); break;
-      case 2: dx_img_class<NT, 2>(g, c, offs.dnb[cls], Z, ZS, tapd, tapuv, wl, dxn, imgs_here, zero_at); break;
-      case 4: dx_img_class<NT, 4>(g, c, offs.dnb[cls], Z, ZS, tapd, tapuv, wl, dxn, imgs_here, zero_at); break;
-      case 8: dx_img_class<NT, 8>(g, c, offs.dnb[cls], Z, ZS, tapd, tapuv, wl, dxn, imgs_here, zero_at); break;
-      default: dx_img_class<NT, 0>(g, c, offs.dnb[cls], Z, ZS, tapd, tapuv, wl, dxn, imgs_here, zero_at); break;
+      case 1: dx_img_class<NT, 1>(g, c, offs.dnb[cls], Z, ZS, tapd, tapuv, wl, dxn, imgs_here, zero_at, xen); break;
+      case 2: dx_img_class<NT, 2>(g, c, offs.dnb[cls], Z, ZS, tapd, tapuv, wl, dxn, imgs_here, zero_at, xen); break;
+      case 4: dx_img_class<NT, 4>(g, c, offs.dnb[cls], Z, ZS, tapd, tapuv, wl, dxn, imgs_here, zero_at, xen); break;
+      case 8: dx_img_class<NT, 8>(g, c, offs.dnb[cls], Z, ZS, tapd, tapuv, wl, dxn, imgs_here, zero_at, xen); break;
+      default: dx_img_class<NT, 0>(g, c, offs.dnb[cls], Z, ZS, tapd, tapuv, wl, dxn, imgs_here, zero_at, xen); break;
     }
   }
 }
@@ -2013,11 +2035,10 @@ int rlgan_elu_backward(const float* dy, const float* y, float* dz, int64_t n, vo
   return launched();
 }
 
-int rlgan_conv_backward_input(const rlgan_conv_t* conv, const float* dz, const float* y_elu, const float* w_canon, const float* wdx,
-                              float* dx, int n_images, void* stream) {
-  ConvG g;
-  if (!make_conv(conv, g)) return RLGAN_E_DIMS;
-  if (!dz || (!w_canon && !wdx) || !dx || n_images <= 0) return RLGAN_E_ARG;
+// x_elu (optional): dx leaves multiplied by ELU'(x_elu); *fused says whether the kernel that ran did that itself
+static int conv_dx_launch(const ConvG& g, const float* dz, const float* y_elu, const float* w_canon, const float* wdx, float* dx,
+                          const float* x_elu, bool* fused, int n_images, void* stream) {
+  *fused = false;
   if (g.Cin == 4 && w_canon && g.s <= 4) {
     C4Off o;
     int most = 0;
@@ -2053,7 +2074,7 @@ int rlgan_conv_backward_input(const rlgan_conv_t* conv, const float* dz, const f
     while (ipw > 1 && cdiv(n_images, ipw) < 512) --ipw;
     const size_t ilds = ipw * zimg + (g.Cout + 4) * sizeof(float) + tabs;    // the images, a row of zeros, the tap tables
     const bool few = n_images < 64;     // not even a workgroup per four compute units: the per-pixel-group kernel below spreads wider
-    if (!few && ntc <= 2 && offs.max_ng * ntc <= DXI_MAXF && ilds <= 64 * 1024 && !(((uintptr_t)dx | (uintptr_t)dz | (uintptr_t)y_elu) & 15)) {
+    if (!few && ntc <= 2 && offs.max_ng * ntc <= DXI_MAXF && ilds <= 64 * 1024 && !(((uintptr_t)dx | (uintptr_t)dz | (uintptr_t)y_elu | (uintptr_t)x_elu) & 15)) {
       // pixels no class covers (stride beyond the kernel) keep the zeros of the other kernel's classes: every class
       // with taps writes all of its pixels, a class without taps (NG == 0) must still be cleared
       bool all_have_taps = true;
@@ -2061,30 +2082,52 @@ int rlgan_conv_backward_input(const rlgan_conv_t* conv, const float* dz, const f
       if (all_have_taps) {
         hipStream_t st = (hipStream_t)stream;
         const dim3 gi(cdiv(n_images, ipw));
-        if (ntc == 1) hipLaunchKernelGGL(conv_dx_img_kernel<1>, gi, dim3(256), ilds, st, g, offs, dz, y_elu, wdx, dx, n_images, ipw);
-        else hipLaunchKernelGGL(conv_dx_img_kernel<2>, gi, dim3(256), ilds, st, g, offs, dz, y_elu, wdx, dx, n_images, ipw);
+        if (ntc == 1) hipLaunchKernelGGL(conv_dx_img_kernel<1>, gi, dim3(256), ilds, st, g, offs, dz, y_elu, wdx, dx, n_images, ipw, x_elu);
+        else hipLaunchKernelGGL(conv_dx_img_kernel<2>, gi, dim3(256), ilds, st, g, offs, dz, y_elu, wdx, dx, n_images, ipw, x_elu);
+        *fused = true;
         return launched();
       }
     }
     const long long per = (long long)cdiv(g.H, g.s) * cdiv(g.W, g.s);          // pixels per image of the largest class
-    if ((long long)n_images * per > 0x7fffffffll || ((uintptr_t)dx & 15)) return RLGAN_E_ALIGN;
+    if ((long long)n_images * per > 0x7fffffffll || (((uintptr_t)dx | (uintptr_t)x_elu) & 15)) return RLGAN_E_ALIGN;
     const long long groups = cdiv((long long)n_images * per, 64);
     const dim3 grid((unsigned)groups, g.s * g.s), block(256);
     const size_t lds = (size_t)std::max(1, offs.max_ng) * 4 * 2 * sizeof(int);
     if (lds > 64 * 1024) return RLGAN_E_DIMS;
     hipStream_t st = (hipStream_t)stream;
     switch (cdiv(g.Cin, 16)) {
-      case 1: hipLaunchKernelGGL(conv_dx_kernel<1>, grid, block, lds, st, g, offs, dz, y_elu, wdx, dx, n_images); break;
-      case 2: hipLaunchKernelGGL(conv_dx_kernel<2>, grid, block, lds, st, g, offs, dz, y_elu, wdx, dx, n_images); break;
-      case 3: hipLaunchKernelGGL(conv_dx_kernel<3>, grid, block, lds, st, g, offs, dz, y_elu, wdx, dx, n_images); break;
-      default: hipLaunchKernelGGL(conv_dx_kernel<4>, grid, block, lds, st, g, offs, dz, y_elu, wdx, dx, n_images); break;
+      case 1: hipLaunchKernelGGL(conv_dx_kernel<1>, grid, block, lds, st, g, offs, dz, y_elu, wdx, dx, n_images, x_elu); break;
+      case 2: hipLaunchKernelGGL(conv_dx_kernel<2>, grid, block, lds, st, g, offs, dz, y_elu, wdx, dx, n_images, x_elu); break;
+      case 3: hipLaunchKernelGGL(conv_dx_kernel<3>, grid, block, lds, st, g, offs, dz, y_elu, wdx, dx, n_images, x_elu); break;
+      default: hipLaunchKernelGGL(conv_dx_kernel<4>, grid, block, lds, st, g, offs, dz, y_elu, wdx, dx, n_images, x_elu); break;
     }
+    *fused = true;
     return launched();
   }
   const size_t total4 = (size_t)n_images * g.H * g.W * (g.Cin / 4);
   hipLaunchKernelGGL(conv_bwd_input_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      g, dz, w_canon, dx, total4);
   return launched();
+}
+
+int rlgan_conv_backward_input_dz(const rlgan_conv_t* conv, const float* dz, const float* y_elu, const float* w_canon, const float* wdx,
+                                 float* dx, const float* x_elu, int n_images, void* stream) {
+  ConvG g;
+  if (!make_conv(conv, g)) return RLGAN_E_DIMS;
+  if (!dz || (!w_canon && !wdx) || !dx || n_images <= 0) return RLGAN_E_ARG;
+  bool fused = false;
+  if (const int rc = conv_dx_launch(g, dz, y_elu, w_canon, wdx, dx, x_elu, &fused, n_images, stream)) return rc;
+  if (x_elu && !fused) {      // a kernel without the factor: one elementwise pass over dx in place
+    const size_t n = (size_t)n_images * g.H * g.W * g.Cin;
+    hipLaunchKernelGGL(elu_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dx, x_elu, dx, n);
+    return launched();
+  }
+  return 0;
+}
+
+int rlgan_conv_backward_input(const rlgan_conv_t* conv, const float* dz, const float* y_elu, const float* w_canon, const float* wdx,
+                              float* dx, int n_images, void* stream) {
+  return rlgan_conv_backward_input_dz(conv, dz, y_elu, w_canon, wdx, dx, nullptr, n_images, stream);
 }
 
 int rlgan_conv_backward_weights(const rlgan_conv_t* conv, const float* x, const float* dz, const float* y_elu, float* slabs,

@@ -149,6 +149,31 @@ def test_dense_products_with_a_width_that_is_not_a_multiple_of_four(m, k, ldx, n
     close(g[k], dz.astype(np.float64).sum(0), what="db, odd k")
 
 
+@pytest.mark.parametrize("n", [6, 200])
+def test_dz_handed_from_the_layer_above(n):
+    """A layer's input gradient multiplied by ELU'(its input) inside the kernel is the dZ of the layer below: the same bits
+    as the product formed afterwards, and the layer below, given that dZ, leaves the gradients it computes from (dY, y)
+    (`universe_feature_abstraction`, Conv_model.py:36-49: 42x42x4 -> 20x20x32 -> 9x9x32)."""
+    import rl_gan_amd as R
+    from rl_gan_amd import _lib
+    rng = np.random.RandomState(n)
+    L1 = R.ConvLayer(42, 42, 4, 32, 3, 2, rng=rng, bias_init=0.01)
+    L2 = R.ConvLayer(20, 20, 32, 32, 3, 2, rng=rng, bias_init=0.01)
+    x = torch.from_numpy(rng.standard_normal((n, 42, 42, 4)).astype(np.float32)).cuda()
+    y1 = L1.forward(x)
+    y2 = L2.forward(y1)
+    dy2 = torch.from_numpy(rng.standard_normal(tuple(y2.shape)).astype(np.float32)).cuda()
+    dy1 = L2.backward(y1, y2, dy2)
+    dz1 = torch.empty_like(dy1)
+    assert _lib.lib.rlgan_elu_backward(dy1.data_ptr(), y1.data_ptr(), dz1.data_ptr(), dy1.numel(), None) == 0
+    got = L2.backward(y1, y2, dy2, dx_elu=True)
+    assert torch.equal(got, dz1)
+    dx_ref = L1.backward(x, y1, dy1)
+    g_ref = L1.grad.clone()
+    dx = L1.backward(x, y1, dz1, dy_is_dz=True)
+    assert torch.equal(L1.grad, g_ref) and torch.equal(dx, dx_ref)
+
+
 def test_encoder_with_dense_head_end_to_end():
     """doom head + fc(256): features, and the gradient reaching the first conv layer."""
     import rl_gan_amd as R
