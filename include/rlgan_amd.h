@@ -559,6 +559,13 @@ int rlgan_deconv_fused_forward(const rlgan_deconv_t* deconv, const float* x, con
  * dx (may be NULL) = input gradient [n, h, w, c_in].  workspace: rlgan_deconv_fused_workspace floats. */
 int rlgan_deconv_fused_backward(const rlgan_deconv_t* deconv, const float* x, const float* y_relu, const float* dy,
                                 const float* wfb, float* dx, float* workspace, float* grad, int n_images, void* stream);
+/* The same with dx_relu: 1 = dx leaves multiplied by ReLU'(x) (x is the ReLU output of the layer below), i.e. as that
+ * layer's dZ; its backward call then takes y_relu = NULL and does not read its output again.  For the 19x19x32 ->
+ * 42x42x1 layer (kind 2), whose kernel holds x in LDS anyway; RLGAN_E_DIMS for the others.  dx * ReLU'(x) is the product
+ * the layer below formed while reading: the same bits. */
+int rlgan_deconv_fused_backward_dz(const rlgan_deconv_t* deconv, const float* x, const float* y_relu, const float* dy,
+                                   const float* wfb, float* dx, int dx_relu, float* workspace, float* grad, int n_images,
+                                   void* stream);
 
 /* ---- glue of the pixel generator's training step (Conv_model.py:437-456,522-541) ------------------------
  * dz = dy * ReLU'(y)   (tf.nn.relu after the generator's first layer, Conv_model.py:455) */

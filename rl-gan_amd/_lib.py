@@ -205,6 +205,7 @@ PROTOTYPES = {
     "rlgan_deconv_fused_build_maps": [C.POINTER(Deconv), _vp, _vp],
     "rlgan_deconv_fused_forward": [C.POINTER(Deconv), _vp, _vp, _vp, _vp, _i, _i, _vp],
     "rlgan_deconv_fused_backward": [C.POINTER(Deconv), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
+    "rlgan_deconv_fused_backward_dz": [C.POINTER(Deconv), _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp],
     "rlgan_column_sums": [_vp, _vp, C.c_int64, _i, _vp, _vp, _vp],
     "rlgan_column_sums_noalloc": [_vp, _vp, C.c_int64, _i, _vp, _vp],
     "rlgan_noalloc_init": [],

@@ -564,7 +564,7 @@ template <class N, bool DX>
 __global__ __launch_bounds__(NBW * 64, NBW / 2) void deconv_narrow_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                                  const float* __restrict__ yact, const float* __restrict__ wfb,
                                                                  float* __restrict__ dx, float* __restrict__ slabs,
-                                                                 int n_images, int per_chunk) {
+                                                                 int n_images, int per_chunk, int dx_relu) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* Dimg = lds;                                       // [NO] dZ of the image
   float* Xt = lds + N::NO;                                 // [PP / 4][CI][4 pixels], zero beyond the image
@@ -638,6 +638,11 @@ __global__ __launch_bounds__(NBW * 64, NBW / 2) void deconv_narrow_bwd_kernel(co
     __syncthreads();
     if (n + 1 < n1) fetch(n + 1);
     for (int t = wave; t < N::MT; t += NBW) {
+      // this lane's input values: pixels 16 t + 4 q .. + 3 of channels 16 nt + j (the weight gradient's operand, and
+      // the ReLU' factor of the input gradient when the layer below is to receive its dZ)
+      f32x4 bx[N::NTC];
+#pragma unroll
+      for (int nt = 0; nt < N::NTC; ++nt) bx[nt] = *(const f32x4*)(Xt + ((4 * t + q) * N::CI + 16 * nt + j) * 4);
       if (DX) {
         const int pb = pixtab[16 * t + j];
         f32x4 accx[N::NTC];
@@ -655,14 +660,11 @@ __global__ __launch_bounds__(NBW * 64, NBW / 2) void deconv_narrow_bwd_kernel(co
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int px = 16 * t + 4 * q + r;
-            if (px < N::P) dxn[px * N::CI + 16 * nt] = accx[nt][r];
+            if (px < N::P) dxn[px * N::CI + 16 * nt] = dx_relu ? accx[nt][r] * relu_d(bx[nt][r]) : accx[nt][r];
           }
         }
       }
       const i32x4 pt = *(const i32x4*)(pixtab + 16 * t + 4 * q);
-      f32x4 bx[N::NTC];
-#pragma unroll
-      for (int nt = 0; nt < N::NTC; ++nt) bx[nt] = *(const f32x4*)(Xt + ((4 * t + q) * N::CI + 16 * nt + j) * 4);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
 #pragma unroll
@@ -823,8 +825,14 @@ int rlgan_deconv_fused_forward(const rlgan_deconv_t* d, const float* x, const fl
 
 int rlgan_deconv_fused_backward(const rlgan_deconv_t* d, const float* x, const float* y_relu, const float* dy, const float* wfb,
                                 float* dx, float* workspace, float* grad, int n_images, void* stream) {
+  return rlgan_deconv_fused_backward_dz(d, x, y_relu, dy, wfb, dx, 0, workspace, grad, n_images, stream);
+}
+
+int rlgan_deconv_fused_backward_dz(const rlgan_deconv_t* d, const float* x, const float* y_relu, const float* dy, const float* wfb,
+                                   float* dx, int dx_relu, float* workspace, float* grad, int n_images, void* stream) {
   const int kind = fused_kind(d);
   if (kind == FUSED_NONE || kind == FUSED_FEW_FWD) return RLGAN_E_DIMS;
+  if (dx_relu && (kind != FUSED_NARROW || !dx)) return RLGAN_E_DIMS;   // the narrow layer's kernel holds its input in LDS; the tile layer's does not
   if (!x || !dy || !wfb || !workspace || !grad || n_images <= 0) return RLGAN_E_ARG;
   if (((uintptr_t)x | (uintptr_t)y_relu | (uintptr_t)dy | (uintptr_t)wfb | (uintptr_t)dx | (uintptr_t)workspace | (uintptr_t)grad) & 15)
     return RLGAN_E_ALIGN;
@@ -851,10 +859,10 @@ int rlgan_deconv_fused_backward(const rlgan_deconv_t* d, const float* x, const f
   float* colsum_scratch = slabs + (size_t)nch * Last::KW;
   if (dx) {
     hipLaunchKernelGGL((deconv_narrow_bwd_kernel<Last, true>), dim3(nch), dim3(NBW * 64), Last::BWD_LDS, st, x, dy, y_relu, wfb, dx, slabs,
-                       n_images, per);
+                       n_images, per, dx_relu);
   } else {
     hipLaunchKernelGGL((deconv_narrow_bwd_kernel<Last, false>), dim3(nch), dim3(NBW * 64), Last::BWD_LDS, st, x, dy, y_relu, wfb, dx, slabs,
-                       n_images, per);
+                       n_images, per, 0);
   }
   if (const int rc = launched()) return rc;
   hipLaunchKernelGGL(slab_sum_kernel, dim3(cdiv(Last::KW, 256)), dim3(256), 0, st, slabs, nch, Last::KW, grad);

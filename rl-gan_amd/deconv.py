@@ -51,6 +51,7 @@ class DeconvLayer:
         check(lib.rlgan_deconv_fused_geometry(self.spec, C.byref(fg)), "rlgan_deconv_fused_geometry")
         self.fused = fg.kind != 0 and fused                  # forward pass by a fused kernel
         self.fused_bwd = self.fused and fg.kind != 3          # kind 3: forward only, the backward pass keeps the cols form
+        self.hands_dz = self.fused_bwd and fg.kind == 2       # its backward kernel can return dx * ReLU'(x): the dZ of the layer below
         if self.fused:
             mf, mb = np.empty(self.n_params, np.int32), np.empty(self.n_params, np.int32)
             check(lib.rlgan_deconv_fused_build_maps(self.spec, mf.ctypes.data, mb.ctypes.data if self.fused_bwd else None),
@@ -119,8 +120,11 @@ class DeconvLayer:
               "rlgan_deconv_place")
         return y
 
-    def backward(self, x: torch.Tensor, y: torch.Tensor, dy: torch.Tensor, need_dx: bool = True, act: bool = True):
-        """Gradients of this layer: fills self.grad (kernel then bias), returns dx or None."""
+    def backward(self, x: torch.Tensor, y: torch.Tensor, dy: torch.Tensor, need_dx: bool = True, act: bool = True,
+                 dx_relu: bool = False):
+        """Gradients of this layer: fills self.grad (kernel then bias), returns dx or None.  dx_relu (see `hands_dz`): the
+        returned gradient is multiplied by ReLU'(x), i.e. it is the dZ of the layer below, which is then called with
+        act=False."""
         n = x.shape[0]
         rows = n * self.h * self.w
         yr = y.data_ptr() if act else None
@@ -129,10 +133,12 @@ class DeconvLayer:
             if self._ws is None or self._ws.numel() < need:
                 self._ws = torch.empty(need, dtype=torch.float32, device=x.device)
             dx = torch.empty_like(x) if need_dx else None
-            check(lib.rlgan_deconv_fused_backward(self.spec, x.data_ptr(), yr, dy.data_ptr(), self.wdx.data_ptr(),
-                                                  None if dx is None else dx.data_ptr(), self._ws.data_ptr(), self.grad.data_ptr(), n,
-                                                  _stream()), "rlgan_deconv_fused_backward")
+            assert not dx_relu or (self.hands_dz and dx is not None)
+            check(lib.rlgan_deconv_fused_backward_dz(self.spec, x.data_ptr(), yr, dy.data_ptr(), self.wdx.data_ptr(),
+                                                     None if dx is None else dx.data_ptr(), 1 if dx_relu else 0, self._ws.data_ptr(),
+                                                     self.grad.data_ptr(), n, _stream()), "rlgan_deconv_fused_backward_dz")
             return dx
+        assert not dx_relu
         # dcols[(n, iy, ix)][(ky, kx, co)] is an element of dz = dy * ReLU'(y): where the layer's extents are whole tiles the
         # two products below read dz in place and the matrix is never written
         view = self.cols_view and lib.rlgan_deconv_view_ok(self.spec, n) == 1
@@ -204,6 +210,10 @@ class Decoder:
         """Backpropagates d(loss)/d(image); every layer's .grad is filled; returns d(loss)/d(code) [n, c]."""
         dy = dimage.contiguous()
         last = len(self.layers) - 1
+        is_dz = False                                             # dy is dZ already: the layer above applied this layer's ReLU'
         for i in range(last, -1, -1):
-            dy = self.layers[i].backward(self._acts[i], self._acts[i + 1], dy, need_dx=need_dx or i > 0, act=i < last)
+            L = self.layers[i]
+            hand = i > 0 and L.hands_dz                           # layer i - 1 has a ReLU (every layer but the last does)
+            dy = L.backward(self._acts[i], self._acts[i + 1], dy, need_dx=need_dx or i > 0, act=i < last and not is_dz, dx_relu=hand)
+            is_dz = hand
         return None if dy is None else dy.reshape(dy.shape[0], -1)
