@@ -106,10 +106,21 @@ __global__ __launch_bounds__(256) void colsum_part_kernel(const float* __restric
   const long long r0 = (long long)blockIdx.x * rows_per_wg, r1 = min(rows, r0 + rows_per_wg);
   float s = 0.f;
   if (ph < phases) {
-    for (long long r = r0 + ph; r < r1; r += phases) {
-      float d = dy[r * C + c];
-      if (yact) d *= relu_d(yact[r * C + c]);
-      s += d;
+    // eight rows' loads requested per turn, added in row order (a row per turn left the compiler's unrolling to cover the
+    // memory latency: the one-channel layer's 7 M rows took 27 us for 29 MB)
+    constexpr int FL = 8;
+    for (long long r = r0 + ph; r < r1; r += (long long)phases * FL) {
+      float d[FL], yv[FL];
+#pragma unroll
+      for (int u = 0; u < FL; ++u) {
+        const long long rr = min(r + (long long)u * phases, r1 - 1);
+        d[u] = dy[rr * C + c];
+        yv[u] = yact ? yact[rr * C + c] : 1.f;
+      }
+#pragma unroll
+      for (int u = 0; u < FL; ++u) {
+        if (r + (long long)u * phases < r1) s += yact ? d[u] * relu_d(yv[u]) : d[u];
+      }
     }
   }
   sh[threadIdx.x] = s;
