@@ -127,6 +127,34 @@ __global__ __launch_bounds__(256) void frames_gather_channel_kernel(const uint8_
     dst[p] = ok ? (float)src[(size_t)p * channels] * scale : 0.f;
 }
 
+// The same for four channels and a pixel count that is a multiple of four: a thread reads four pixels (16 bytes),
+// picks the channel's byte of each and writes four floats (a byte per load and a float per store: 23 us for 4096
+// frames of 42x42; the workgroup is one frame, 441 threads' worth of work).
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void frames_gather_channel4_kernel(const uint8_t* __restrict__ ring, long long slots, int quads,
+                                                                     int channel, const int64_t* __restrict__ idx, float scale,
+                                                                     float* __restrict__ out) {
+  const long long slot = idx[blockIdx.x];
+  const bool ok = slot >= 0 && slot < slots;
+  const u32x4* src = (const u32x4*)(ring + (size_t)(ok ? slot : 0) * quads * 16);
+  f32x4* dst = (f32x4*)out + (size_t)blockIdx.x * quads;
+  const int sh = 8 * channel;
+  constexpr int U = 2;
+  for (int q0 = threadIdx.x; q0 < quads; q0 += 256 * U) {
+    u32x4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = src[min(q0 + 256 * u, quads - 1)];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (q0 + 256 * u < quads) {
+        const f32x4 f{(float)((v[u][0] >> sh) & 255u) * scale, (float)((v[u][1] >> sh) & 255u) * scale,
+                      (float)((v[u][2] >> sh) & 255u) * scale, (float)((v[u][3] >> sh) & 255u) * scale};
+        dst[q0 + 256 * u] = ok ? f : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -206,6 +234,11 @@ int rlgan_frames_gather_channel(const uint8_t* ring, int64_t slots, int32_t pixe
                                 const int64_t* idx, int32_t n, float scale, float* out, void* stream) {
   if (!ring || !idx || !out || slots <= 0 || pixels <= 0 || n <= 0 || n > 65535) return RLGAN_E_ARG;
   if (channels <= 0 || channel < 0 || channel >= channels) return RLGAN_E_DIMS;
+  if (channels == 4 && pixels % 4 == 0 && !(((uintptr_t)ring | (uintptr_t)out) & 15)) {
+    hipLaunchKernelGGL(frames_gather_channel4_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, ring, (long long)slots, pixels / 4,
+                       channel, idx, scale, out);
+    return launched();
+  }
   hipLaunchKernelGGL(frames_gather_channel_kernel, dim3(std::min(cdiv(pixels, 256), 64), n), dim3(256), 0, (hipStream_t)stream,
                      ring, (long long)slots, pixels, channels, channel, idx, scale, out);
   return launched();
