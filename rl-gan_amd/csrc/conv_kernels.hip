@@ -1012,7 +1012,8 @@ __device__ __forceinline__ void dx_img_class(const ConvG& g, const DxClass& c, F
     const int pz = (img * g.Ho * g.Wo + a * g.Wo + bb) * ZS;
     float* dxn = dx0 + (size_t)img * g.H * g.W * g.Cin;
     // The layer input at this lane's result (xe0: the ELU output of the layer below), requested before the gathers; the
-    // result leaves as that layer's dZ.  (Requested a whole tile ahead instead: no change.  Probe builds: the reads cost
+    // result leaves as that layer's dZ.  (Requested a whole tile ahead instead: no change; two tiles per turn for the
+    // classes with one or two taps, their gathers requested together: no change either.  Probe builds: the reads cost
     // the kernel 38 us per 4096 maps of 20x20x32, the multiplications nothing -- the 210 MB move here from the layer
     // below's two backward kernels, which are bound by memory, and cost less here than there.)
     const size_t oo = (size_t)img * g.H * g.W * g.Cin + ((size_t)(g.s * a + c.py) * g.W + (g.s * bb + c.px)) * g.Cin;
