@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void conv_fwd_static_kernel(const ConvG g, con
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, 0x7fffffff, 0x00020000);
   const int ntiles = (M + 15) / 16, per_wg = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
   const int t_end = min(ntiles, ((int)blockIdx.x + 1) * per_wg);
-  int tile = __builtin_amdgcn_readfirstlane((int)blockIdx.x * per_wg + wave);
+  int tile = __builtin_amdgcn_readfirstlane((int)blockIdx.x * per_wg + wave);   // (the first wave turning with the workgroup, so that a share of 6 + 5 + 5 + 5 tiles does not always favour one SIMD: no change)
   if (tile >= t_end) return;                              // no barrier follows
   const float* wl = wlds + lane * 4;
   const int img_bytes = g.H * g.W * g.Cin * 4;
