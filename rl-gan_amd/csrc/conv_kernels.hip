@@ -254,6 +254,8 @@ __global__ __launch_bounds__(256) void conv_fwd_static_kernel(const ConvG g, con
       if (c + 1 < NCH) fetch(cur, c + 1, a[(c + 1) & 1]);
       else fetch(nxt, 0, a[0]);
       __builtin_amdgcn_sched_barrier(0);                  // keep the fetches ahead of this chunk's products
+      // (the weight fragments of group gi + 1 read from LDS before the products of group gi, order pinned: no change --
+      // with four waves per SIMD the other waves cover a group's LDS latency)
 #pragma unroll
       for (int u = 0; u < PF; ++u) {
         const int gi = c * PF + u;
