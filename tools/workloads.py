@@ -192,6 +192,7 @@ def pixel_curious_gan(B=4096, a_dim=6):
     def step():
         tr.sample()
         tr.step()
+    step.trainer = tr                                       # for tools/soak_pixel.py
     return step
 
 
