@@ -151,6 +151,10 @@ __device__ __forceinline__ void tile_load_view(f32x4 (&r)[TL], const float* __re
 // Position of reduction index k in row x of an LDS tile: the row's eight 4-float groups are permuted by the row's
 // 16-row block (k ^ 0, 4, 8 or 12).  A 16-byte operand read stays one aligned group; the transposing store below,
 // whose sixteen x-quads per k would otherwise fall on four banks four deep, spreads over all 64 banks.
+// (Rows of 32 floats without padding, the groups permuted by (x >> 1) & 7 instead: the weight product with few slabs
+// runs a third faster, 484 -> 324 us unsplit at 8192 x 2593 -> 256, but at the slab counts in use it is 2 % slower and
+// the forward product 6 % slower; the LDS counters show conflicts in a third to a half of this kernel's LDS cycles
+// with either layout.)
 __device__ __forceinline__ int swz(int x, int k) { return k ^ (((x >> 4) & 3) << 2); }
 // the registers of tile_load into an LDS tile [64 x][LDT], k contiguous
 template <bool KCONT>
