@@ -1,3 +1,6 @@
+    allow_lds(deconv_tile_fwd_kernel<Mid, 2>, Mid::FWD_LDS);
+    hipLaunchKernelGGL((deconv_tile_fwd_kernel<Mid, 2>), dim3(cdiv(n_images, Mid::IPW)), dim3(512), Mid::FWD_LDS, (hipStream_t)stream,
+                       x, wff, bias, y, n_images, act_relu);
 // Stride-2 transposed convolutions of the pixel generator's decoder (Conv_model.py:457-473) without the `cols`
 // matrix in memory, for the two layer shapes that carry most of the decoder's time:
 //
@@ -58,34 +61,31 @@ using Mid = TileT<8, 64, 32, 5>;
 // pixels (oy = 2 iy + ky).  Side 0 of a pair of waves takes the taps with ky + kx even, side 1 the others (13 and 12
 // of the 25 taps of a 5x5 kernel): the two add into one output tile at the same time without ever meeting in an
 // element, and every element still receives its taps in ascending order.
-// (Three sides -- the classes as 9, 6 + 4 and 6 taps, three waves per SIMD -- measured no faster than two: 261 against 259 us.)
-#ifndef RLGAN_TILE_SIDES
-#define RLGAN_TILE_SIDES 2
-#endif
-constexpr int TILE_SIDES = RLGAN_TILE_SIDES;
-template <class T> __host__ __device__ constexpr int tile_side_of(int tap) {
+// NS sides: two are used.  (Three -- the classes as 9, 6 + 4 and 6 taps, three waves per SIMD -- are no faster: 261 against
+// 259 us at 4096 images, and the iteration at 32 images, where a workgroup is a chain of dependent products, 1.012 -> 1.010 ms.)
+template <class T, int NS> __host__ __device__ constexpr int tile_side_of(int tap) {
   const int ky = tap / T::K, kx = tap % T::K;
-  if (TILE_SIDES == 2) return (ky + kx) & 1;
+  if (NS == 2) return (ky + kx) & 1;
   const int cls = (ky & 1) * 2 + (kx & 1);
   return cls == 0 ? 0 : cls == 2 ? 2 : 1;
 }
-template <class T> __host__ __device__ constexpr int tile_side_taps(int side) {
+template <class T, int NS> __host__ __device__ constexpr int tile_side_taps(int side) {
   int n = 0;
-  for (int tap = 0; tap < T::TAPS; ++tap) n += tile_side_of<T>(tap) == side;
+  for (int tap = 0; tap < T::TAPS; ++tap) n += tile_side_of<T, NS>(tap) == side;
   return n;
 }
-template <class T> __host__ __device__ constexpr int tile_side_tap(int side, int i) {
+template <class T, int NS> __host__ __device__ constexpr int tile_side_tap(int side, int i) {
   for (int tap = 0; tap < T::TAPS; ++tap) {
-    if (tile_side_of<T>(tap) == side && i-- == 0) return tap;
+    if (tile_side_of<T, NS>(tap) == side && i-- == 0) return tap;
   }
   return T::TAPS;
 }
-template <class T, int SIDE>
+template <class T, int NS, int SIDE>
 __device__ __forceinline__ void tile_fwd_taps(const f32x4 (&a)[T::MT][T::KG], float* Y, const int (&po)[T::MT][4], const FragSrc& ws) {
-  constexpr int N = tile_side_taps<T>(SIDE);
+  constexpr int N = tile_side_taps<T, NS>(SIDE);
   f32x4 b[2][T::KG];
 #pragma unroll
-  for (int g = 0; g < T::KG; ++g) b[0][g] = ws.load(tile_side_tap<T>(SIDE, 0) * T::CT * T::KG + g);
+  for (int g = 0; g < T::KG; ++g) b[0][g] = ws.load(tile_side_tap<T, NS>(SIDE, 0) * T::CT * T::KG + g);
   f32x4 prev[T::MT];
 #pragma unroll
   for (int i = 0; i <= N; ++i) {
@@ -93,7 +93,7 @@ __device__ __forceinline__ void tile_fwd_taps(const f32x4 (&a)[T::MT][T::KG], fl
     if (i < N) {
       if (i + 1 < N) {
 #pragma unroll
-        for (int g = 0; g < T::KG; ++g) b[(i + 1) & 1][g] = ws.load(tile_side_tap<T>(SIDE, i + 1) * T::CT * T::KG + g);
+        for (int g = 0; g < T::KG; ++g) b[(i + 1) & 1][g] = ws.load(tile_side_tap<T, NS>(SIDE, i + 1) * T::CT * T::KG + g);
       }
 #pragma unroll
       for (int t = 0; t < T::MT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -108,7 +108,7 @@ __device__ __forceinline__ void tile_fwd_taps(const f32x4 (&a)[T::MT][T::KG], fl
     }
     if (i > 0) {
       // the previous tap's products go to their output pixels while this tap's MFMAs run
-      const int tap = tile_side_tap<T>(SIDE, i - 1);
+      const int tap = tile_side_tap<T, NS>(SIDE, i - 1);
       const int off = ((tap / T::K) * T::HO + tap % T::K) * 16;
 #pragma unroll
       for (int t = 0; t < T::MT; ++t) {
@@ -126,8 +126,8 @@ __device__ __forceinline__ void tile_fwd_taps(const f32x4 (&a)[T::MT][T::KG], fl
 // SIMD) are the two sides of (image, channel tile) w, so each SIMD has one wave's additions into LDS, its first
 // loads and its last stores to run under the other's products.  (With one wave per tile, all taps in a row, the
 // matrix pipe stood idle for 15 of the 40 us a workgroup took.)
-template <class T>
-__global__ __launch_bounds__(256 * TILE_SIDES) void deconv_tile_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wff,
+template <class T, int NS>
+__global__ __launch_bounds__(256 * NS) void deconv_tile_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wff,
                                                                const float* __restrict__ bias, float* __restrict__ y,
                                                                int n_images, int act) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256 * TILE_SIDES) void deconv_tile_fwd_kernel(const
     for (int g = 0; g < T::KG; ++g) a[t][g] = *(const f32x4*)(xn + (16 * t + j) * T::CI + 16 * g + 4 * q);
   }
   const f32x4 b4 = *(const f32x4*)(bias + 16 * c + 4 * (lane & 3));
-  for (int i = lane + 64 * side; i < T::NPIX * 4; i += 64 * TILE_SIDES) ((f32x4*)Y)[i] = b4;
+  for (int i = lane + 64 * side; i < T::NPIX * 4; i += 64 * NS) ((f32x4*)Y)[i] = b4;
   // LDS position of accumulator element (t, r) = input pixel 16 t + 4 q + r, channel j, for tap (0, 0)
   int po[T::MT][4];
 #pragma unroll
@@ -159,13 +159,13 @@ __global__ __launch_bounds__(256 * TILE_SIDES) void deconv_tile_fwd_kernel(const
     }
   }
   __syncthreads();                                         // both sides' halves of the bias are in place
-  if (side == 0) tile_fwd_taps<T, 0>(a, Y, po, ws);
-  else if (side == 1) tile_fwd_taps<T, 1>(a, Y, po, ws);
-  else tile_fwd_taps<T, TILE_SIDES - 1>(a, Y, po, ws);
+  if (side == 0) tile_fwd_taps<T, NS, 0>(a, Y, po, ws);
+  else if (side == 1) tile_fwd_taps<T, NS, 1>(a, Y, po, ws);
+  else tile_fwd_taps<T, NS, NS - 1>(a, Y, po, ws);
   __syncthreads();
   if (!live) return;
   float* yn = y + (size_t)n * T::NPIX * T::CO + 16 * c + 4 * (lane & 3);
-  for (int i = lane + 64 * side; i < T::NPIX * 4; i += 64 * TILE_SIDES) {
+  for (int i = lane + 64 * side; i < T::NPIX * 4; i += 64 * NS) {
     f32x4 v = ((const f32x4*)Y)[i];
     if (act) v = f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
     *(f32x4*)(yn + (size_t)(i >> 2) * T::CO) = v;
@@ -808,9 +808,16 @@ int rlgan_deconv_fused_forward(const rlgan_deconv_t* d, const float* x, const fl
   if (!x || !wff || !bias || !y || n_images <= 0) return RLGAN_E_ARG;
   if (((uintptr_t)x | (uintptr_t)wff | (uintptr_t)bias | (uintptr_t)y) & 15) return RLGAN_E_ALIGN;
   if (kind == FUSED_TILE) {
-    allow_lds(deconv_tile_fwd_kernel<Mid>, Mid::FWD_LDS);
-    hipLaunchKernelGGL(deconv_tile_fwd_kernel<Mid>, dim3(cdiv(n_images, Mid::IPW)), dim3(256 * TILE_SIDES), Mid::FWD_LDS, (hipStream_t)stream,
-                       x, wff, bias, y, n_images, act_relu);
+    // fewer workgroups than compute units: each is a chain, cut three ways instead of two
+    if (cdiv(n_images, Mid::IPW) < 256) {
+      allow_lds(deconv_tile_fwd_kernel<Mid, 3>, Mid::FWD_LDS);
+      hipLaunchKernelGGL((deconv_tile_fwd_kernel<Mid, 3>), dim3(cdiv(n_images, Mid::IPW)), dim3(768), Mid::FWD_LDS, (hipStream_t)stream,
+                         x, wff, bias, y, n_images, act_relu);
+    } else {
+      allow_lds(deconv_tile_fwd_kernel<Mid, 2>, Mid::FWD_LDS);
+      hipLaunchKernelGGL((deconv_tile_fwd_kernel<Mid, 2>), dim3(cdiv(n_images, Mid::IPW)), dim3(512), Mid::FWD_LDS, (hipStream_t)stream,
+                         x, wff, bias, y, n_images, act_relu);
+    }
   } else if (kind == FUSED_FEW_FWD) {
     allow_lds(deconv_few_fwd_kernel<Few>, Few::FWD_LDS);
     hipLaunchKernelGGL(deconv_few_fwd_kernel<Few>, dim3(cdiv(n_images, 16), 4), dim3(512), Few::FWD_LDS, (hipStream_t)stream,
