@@ -1,6 +1,3 @@
-    allow_lds(deconv_tile_fwd_kernel<Mid, 2>, Mid::FWD_LDS);
-    hipLaunchKernelGGL((deconv_tile_fwd_kernel<Mid, 2>), dim3(cdiv(n_images, Mid::IPW)), dim3(512), Mid::FWD_LDS, (hipStream_t)stream,
-                       x, wff, bias, y, n_images, act_relu);
 // Stride-2 transposed convolutions of the pixel generator's decoder (Conv_model.py:457-473) without the `cols`
 // matrix in memory, for the two layer shapes that carry most of the decoder's time:
 //
@@ -808,16 +805,9 @@ int rlgan_deconv_fused_forward(const rlgan_deconv_t* d, const float* x, const fl
   if (!x || !wff || !bias || !y || n_images <= 0) return RLGAN_E_ARG;
   if (((uintptr_t)x | (uintptr_t)wff | (uintptr_t)bias | (uintptr_t)y) & 15) return RLGAN_E_ALIGN;
   if (kind == FUSED_TILE) {
-    // fewer workgroups than compute units: each is a chain, cut three ways instead of two
-    if (cdiv(n_images, Mid::IPW) < 256) {
-      allow_lds(deconv_tile_fwd_kernel<Mid, 3>, Mid::FWD_LDS);
-      hipLaunchKernelGGL((deconv_tile_fwd_kernel<Mid, 3>), dim3(cdiv(n_images, Mid::IPW)), dim3(768), Mid::FWD_LDS, (hipStream_t)stream,
-                         x, wff, bias, y, n_images, act_relu);
-    } else {
-      allow_lds(deconv_tile_fwd_kernel<Mid, 2>, Mid::FWD_LDS);
-      hipLaunchKernelGGL((deconv_tile_fwd_kernel<Mid, 2>), dim3(cdiv(n_images, Mid::IPW)), dim3(512), Mid::FWD_LDS, (hipStream_t)stream,
-                         x, wff, bias, y, n_images, act_relu);
-    }
+    allow_lds(deconv_tile_fwd_kernel<Mid, 2>, Mid::FWD_LDS);
+    hipLaunchKernelGGL((deconv_tile_fwd_kernel<Mid, 2>), dim3(cdiv(n_images, Mid::IPW)), dim3(512), Mid::FWD_LDS, (hipStream_t)stream,
+                       x, wff, bias, y, n_images, act_relu);
   } else if (kind == FUSED_FEW_FWD) {
     allow_lds(deconv_few_fwd_kernel<Few>, Few::FWD_LDS);
     hipLaunchKernelGGL(deconv_few_fwd_kernel<Few>, dim3(cdiv(n_images, 16), 4), dim3(512), Few::FWD_LDS, (hipStream_t)stream,
