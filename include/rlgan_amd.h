@@ -560,9 +560,9 @@ int rlgan_deconv_fused_forward(const rlgan_deconv_t* deconv, const float* x, con
 int rlgan_deconv_fused_backward(const rlgan_deconv_t* deconv, const float* x, const float* y_relu, const float* dy,
                                 const float* wfb, float* dx, float* workspace, float* grad, int n_images, void* stream);
 /* The same with dx_relu: 1 = dx leaves multiplied by ReLU'(x) (x is the ReLU output of the layer below), i.e. as that
- * layer's dZ; its backward call then takes y_relu = NULL and does not read its output again.  For the 19x19x32 ->
- * 42x42x1 layer (kind 2), whose kernel holds x in LDS anyway; RLGAN_E_DIMS for the others.  dx * ReLU'(x) is the product
- * the layer below formed while reading: the same bits. */
+ * layer's dZ; its backward call then takes y_relu = NULL and does not read its output again (kind 2 holds x in LDS
+ * anyway, kind 1 reads it beside its stores).  dx must be given.  dx * ReLU'(x) is the product the layer below formed
+ * while reading: the same bits. */
 int rlgan_deconv_fused_backward_dz(const rlgan_deconv_t* deconv, const float* x, const float* y_relu, const float* dy,
                                    const float* wfb, float* dx, int dx_relu, float* workspace, float* grad, int n_images,
                                    void* stream);

@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256 * NS) void deconv_tile_fwd_kernel(const float* 
 template <class T>
 __global__ __launch_bounds__(256) void deconv_tile_dx_kernel(const float* __restrict__ dy, const float* __restrict__ yact,
                                                               const float* __restrict__ wfb, float* __restrict__ dx,
-                                                              float* __restrict__ bias_part) {
+                                                              float* __restrict__ bias_part, const float* __restrict__ x_relu) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* Z = lds;                                          // [NPIX][ZS]
   float* red = lds + T::NPIX * T::ZS;                      // [256]
@@ -230,10 +230,26 @@ __global__ __launch_bounds__(256) void deconv_tile_dx_kernel(const float* __rest
     if (s + RB < STEPS) b[s % RB] = ws.load(s + RB);
   }
   float* dxn = dx + (size_t)n * T::P * T::CI + 16 * wave + j;
+  if (x_relu) {
+    // the layer input at this lane's results (the ReLU output of the layer below): the gradient leaves as that layer's dZ
+    const float* xn = x_relu + (size_t)n * T::P * T::CI + 16 * wave + j;
+    float xr[T::MT][4];
 #pragma unroll
-  for (int t = 0; t < T::MT; ++t) {
+    for (int t = 0; t < T::MT; ++t) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) dxn[(16 * t + 4 * q + r) * T::CI] = acc[t][r];
+      for (int r = 0; r < 4; ++r) xr[t][r] = xn[(16 * t + 4 * q + r) * T::CI];
+    }
+#pragma unroll
+    for (int t = 0; t < T::MT; ++t) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dxn[(16 * t + 4 * q + r) * T::CI] = acc[t][r] * relu_d(xr[t][r]);
+    }
+  } else {
+#pragma unroll
+    for (int t = 0; t < T::MT; ++t) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dxn[(16 * t + 4 * q + r) * T::CI] = acc[t][r];
+    }
   }
   // bias gradient of this image: thread = (pixel phase, channel), phases added in order
   constexpr int PH = 256 / T::CO;
@@ -829,7 +845,7 @@ int rlgan_deconv_fused_backward_dz(const rlgan_deconv_t* d, const float* x, cons
                                    float* dx, int dx_relu, float* workspace, float* grad, int n_images, void* stream) {
   const int kind = fused_kind(d);
   if (kind == FUSED_NONE || kind == FUSED_FEW_FWD) return RLGAN_E_DIMS;
-  if (dx_relu && (kind != FUSED_NARROW || !dx)) return RLGAN_E_DIMS;   // the narrow layer's kernel holds its input in LDS; the tile layer's does not
+  if (dx_relu && !dx) return RLGAN_E_ARG;
   if (!x || !dy || !wfb || !workspace || !grad || n_images <= 0) return RLGAN_E_ARG;
   if (((uintptr_t)x | (uintptr_t)y_relu | (uintptr_t)dy | (uintptr_t)wfb | (uintptr_t)dx | (uintptr_t)workspace | (uintptr_t)grad) & 15)
     return RLGAN_E_ALIGN;
@@ -845,7 +861,8 @@ int rlgan_deconv_fused_backward_dz(const rlgan_deconv_t* d, const float* x, cons
     hipLaunchKernelGGL(slab_sum_kernel, dim3(cdiv(Mid::KW, 256)), dim3(256), 0, st, slabs, nch, Mid::KW, grad);
     if (const int rc = launched()) return rc;
     if (dx) {
-      hipLaunchKernelGGL(deconv_tile_dx_kernel<Mid>, dim3(n_images), dim3(256), Mid::DX_LDS, st, dy, y_relu, wfb, dx, bias_part);
+      hipLaunchKernelGGL(deconv_tile_dx_kernel<Mid>, dim3(n_images), dim3(256), Mid::DX_LDS, st, dy, y_relu, wfb, dx, bias_part,
+                         dx_relu ? x : nullptr);
       if (const int rc = launched()) return rc;
       return rlgan_column_sums(bias_part, nullptr, n_images, Mid::CO, colsum_scratch, grad + Mid::KW, stream);
     }

@@ -51,7 +51,7 @@ class DeconvLayer:
         check(lib.rlgan_deconv_fused_geometry(self.spec, C.byref(fg)), "rlgan_deconv_fused_geometry")
         self.fused = fg.kind != 0 and fused                  # forward pass by a fused kernel
         self.fused_bwd = self.fused and fg.kind != 3          # kind 3: forward only, the backward pass keeps the cols form
-        self.hands_dz = self.fused_bwd and fg.kind == 2       # its backward kernel can return dx * ReLU'(x): the dZ of the layer below
+        self.hands_dz = self.fused_bwd                        # its backward kernels can return dx * ReLU'(x): the dZ of the layer below
         if self.fused:
             mf, mb = np.empty(self.n_params, np.int32), np.empty(self.n_params, np.int32)
             check(lib.rlgan_deconv_fused_build_maps(self.spec, mf.ctypes.data, mb.ctypes.data if self.fused_bwd else None),
