@@ -174,6 +174,25 @@ def test_dz_handed_from_the_layer_above(n):
     assert torch.equal(L1.grad, g_ref) and torch.equal(dx, dx_ref)
 
 
+@pytest.mark.parametrize("h,cin,cout,k,st,n", [(12, 8, 16, 3, 3, 5), (9, 16, 32, 3, 2, 3), (10, 4, 4, 2, 4, 6), (41, 32, 32, 3, 2, 70)])
+def test_input_gradient_times_elu_prime_of_the_input_on_every_kernel(h, cin, cout, k, st, n):
+    """rlgan_conv_backward_input_dz on shapes that take the other input-gradient kernels (per-pixel-group, four-channel,
+    few images): dx * ELU'(x), the bits of the separate pass, whichever kernel runs and whether it applies the factor
+    itself or an elementwise pass follows."""
+    import rl_gan_amd as R
+    from rl_gan_amd import _lib
+    rng = np.random.RandomState(h + cin)
+    L = R.ConvLayer(h, h, cin, cout, k, st, rng=rng, bias_init=0.01)
+    x = torch.from_numpy(rng.standard_normal((n, h, h, cin)).astype(np.float32)).cuda()
+    y = L.forward(x)
+    dy = torch.from_numpy(rng.standard_normal(tuple(y.shape)).astype(np.float32)).cuda()
+    dx = L.backward(x, y, dy, need_dw=False)
+    want = torch.empty_like(dx)
+    assert _lib.lib.rlgan_elu_backward(dx.data_ptr(), x.data_ptr(), want.data_ptr(), dx.numel(), None) == 0
+    got = L.backward(x, y, dy, need_dw=False, dx_elu=True)
+    assert torch.equal(got, want)
+
+
 def test_encoder_with_dense_head_end_to_end():
     """doom head + fc(256): features, and the gradient reaching the first conv layer."""
     import rl_gan_amd as R
