@@ -89,6 +89,28 @@ def test_backward_products_through_the_cols_view(act, n):
     assert _lib.lib.rlgan_deconv_backward_input_view(L.spec, dyt.data_ptr(), L.wmat.data_ptr(), dx_view.data_ptr(), n - 1, None, 1, None) == -2
 
 
+@pytest.mark.parametrize("n", [3, 64])
+def test_decoder_layers_hand_dz_down(n):
+    """The two fused layers return their input gradient times ReLU'(input) and the layer below skips its own ReLU' (at 64
+    images the few-pixel layer below reads that dZ through the cols view): every gradient and the code gradient keep the
+    bits of the pass in which every layer applies its own ReLU'."""
+    import rl_gan_amd as R
+    rng = np.random.RandomState(n)
+    dec = R.Decoder(200, rng=rng, bias_init=0.01)
+    code = torch.from_numpy(rng.standard_normal((n, 200)).astype(np.float32)).cuda()
+    img = dec.forward(code)
+    d = torch.from_numpy(rng.standard_normal(tuple(img.shape)).astype(np.float32)).cuda()
+    assert any(L.hands_dz for L in dec.layers)
+    dcode = dec.backward(d).clone()
+    grads = [L.grad.clone() for L in dec.layers]
+    for L in dec.layers:
+        L.hands_dz = False
+    dcode2 = dec.backward(d)
+    assert torch.equal(dcode, dcode2)
+    for L, g in zip(dec.layers, grads):
+        assert torch.equal(L.grad, g)
+
+
 def test_decoder_end_to_end():
     import rl_gan_amd as R
     from gpu_util import close
